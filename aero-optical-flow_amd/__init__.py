@@ -1,0 +1,349 @@
+"""Python harness over the C ABI of the MI355X flow engine (include/aof.h).
+
+The product is ``csrc/libaof.so`` (hand-written gfx950 kernels behind a plain C
+ABI) and the C++ facade in ``facade/``; this module only binds the C ABI with
+``ctypes`` so that tests and ``bench.py`` can drive it with device memory owned
+by PyTorch.  It mirrors the reference's operator surface for the path --
+``OpticalFlowPX4.calcFlow`` as called from
+``/root/reference/src/mainloop.cpp:322`` -- in :class:`OpticalFlowPX4`.
+
+There is no CPU fallback anywhere in this package: if ``libaof.so`` is missing
+the import raises, and every compute entry point needs a gfx950 device.
+
+The directory name contains a hyphen, so import it through
+``__graft_entry__.load_package()`` (registers it as ``aero_optical_flow_amd``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libaof.so")
+
+GRID_DENSE, GRID_PX4FLOW = 0, 1
+SAD_SKIPPED = 0xFFFF
+FLAG_FLOW_VALID, FLAG_PRED_VALID = 1, 2
+K_PYRAMID, K_SEARCH_L1, K_REDUCE_L1, K_SEARCH, K_REDUCE = range(5)
+
+BLOCK_DTYPE = np.dtype([("dx", "i1"), ("dy", "i1"), ("sad", "<u2")])
+FLOW_DTYPE = np.dtype([("flow_x", "<f4"), ("flow_y", "<f4"), ("count", "<u4"), ("quality", "u1"),
+                       ("flags", "u1"), ("pred_x", "i1"), ("pred_y", "i1")])
+assert BLOCK_DTYPE.itemsize == 4 and FLOW_DTYPE.itemsize == 16
+
+
+class Params(C.Structure):
+    """``aof_params`` (include/aof.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "width", "height", "tile", "search", "grid_mode", "num_blocks", "feature_threshold",
+        "value_threshold", "subpixel", "hist_filter", "pyramid_levels", "mean_subtract",
+        "min_valid")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class WsLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "total_bytes", "sums", "l1_prev", "l1_cur", "l1_blocks", "l1_subdirs", "l1_flows",
+        "l0_blocks", "l0_subdirs")]
+
+
+class AofError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"aof error {code}: {text}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:  # share torch's HIP runtime instance when torch is in the process
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the facade
+        pass
+    lib = C.CDLL(LIB_PATH)
+    P, VP, I64 = C.POINTER, C.c_void_p, C.c_int64
+    sig = {
+        "aof_version": (C.c_int, []),
+        "aof_strerror": (C.c_char_p, [C.c_int]),
+        "aof_params_default": (C.c_int, [P(Params), C.c_int, C.c_int]),
+        "aof_params_px4flow": (C.c_int, [P(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "aof_params_check": (C.c_int, [P(Params)]),
+        "aof_grid": (C.c_int, [P(Params), C.c_int] + [P(C.c_int32)] * 6),
+        "aof_workspace_layout": (C.c_int, [P(Params), I64, P(WsLayout)]),
+        "aof_create": (C.c_int, [P(Params), C.c_int, P(VP)]),
+        "aof_destroy": (None, [VP]),
+        "aof_last_error": (C.c_char_p, [VP]),
+        "aof_get_params": (C.c_int, [VP, P(Params)]),
+        "aof_search_variant": (C.c_char_p, [VP]),
+        "aof_set_force_generic": (C.c_int, [VP, C.c_int]),
+        "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
+        "aof_flow_pair_host": (C.c_int, [VP, VP, VP, VP, VP, VP]),
+        "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
+        "aof_stream_reset": (C.c_int, [VP]),
+        "aof_set_profiling": (C.c_int, [VP, C.c_int]),
+        "aof_kernel_ms": (C.c_int, [VP, C.c_int, P(C.c_float)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib, tuple(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def default_params(width, height, **overrides) -> Params:
+    p = Params()
+    lib.aof_params_default(C.byref(p), width, height)
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, int(v))
+    return p
+
+
+def px4flow_params(width, height, search=4, feature_threshold=30, value_threshold=3000,
+                   **overrides) -> Params:
+    p = Params()
+    lib.aof_params_px4flow(C.byref(p), width, height, search, feature_threshold, value_threshold)
+    for k, v in overrides.items():
+        setattr(p, k, int(v))
+    return p
+
+
+def check_params(p: Params) -> int:
+    return lib.aof_params_check(C.byref(p))
+
+
+def grid(p: Params, level=0):
+    """(x0, y0, step_x, step_y, nx, ny) of a pyramid level."""
+    v = [C.c_int32() for _ in range(6)]
+    rc = lib.aof_grid(C.byref(p), level, *[C.byref(x) for x in v])
+    if rc:
+        raise AofError(rc, lib.aof_strerror(rc).decode())
+    return tuple(x.value for x in v)
+
+
+def workspace_layout(p: Params, n_pairs: int) -> WsLayout:
+    L = WsLayout()
+    rc = lib.aof_workspace_layout(C.byref(p), n_pairs, C.byref(L))
+    if rc:
+        raise AofError(rc, lib.aof_strerror(rc).decode())
+    return L
+
+
+def algorithmic_bytes(p: Params) -> int:
+    """Compulsory HBM bytes per frame pair:
+    read both frames once, write 4 B per block and the 16 B result."""
+    _, _, _, _, nx, ny = grid(p, 0)
+    return 2 * p.width * p.height + 4 * nx * ny + 16
+
+
+def abs_diffs(p: Params) -> int:
+    _, _, _, _, nx, ny = grid(p, 0)
+    return nx * ny * (2 * p.search + 1) ** 2 * p.tile ** 2
+
+
+class FlowEngine:
+    """One ``aof_ctx``: the batched, device-resident hot path."""
+
+    def __init__(self, params: Params, device: int = 0):
+        self._ctx = C.c_void_p()
+        rc = lib.aof_create(C.byref(params), device, C.byref(self._ctx))
+        if rc:
+            self._ctx = None
+            raise AofError(rc, lib.aof_strerror(rc).decode())
+        self.params = params
+        self.device = device
+        self._ws = None
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib.aof_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise AofError(rc, lib.aof_last_error(self._ctx).decode())
+        return rc
+
+    @property
+    def variant(self) -> str:
+        return lib.aof_search_variant(self._ctx).decode()
+
+    def force_generic(self, on=True):
+        self._check(lib.aof_set_force_generic(self._ctx, int(on)))
+
+    def set_profiling(self, on=True):
+        self._check(lib.aof_set_profiling(self._ctx, int(on)))
+
+    def kernel_ms(self, kernel_id) -> float:
+        ms = C.c_float()
+        self._check(lib.aof_kernel_ms(self._ctx, kernel_id, C.byref(ms)))
+        return ms.value
+
+    def grid(self, level=0):
+        return grid(self.params, level)
+
+    def nblocks(self, level=0):
+        g = self.grid(level)
+        return g[4] * g[5]
+
+    # -- device-resident batch ------------------------------------------------
+    def flow_batch(self, prev, cur, blocks=None, subdirs=None, flows=None, workspace=None,
+                   pair_stride=None, n_pairs=None):
+        """prev/cur: uint8 CUDA tensors [n, H, W] (or any layout described by
+        pair_stride).  Returns (blocks [n, nb] int32-viewed records, flows [n, 16] bytes,
+        workspace).  Everything is enqueued on torch's current stream."""
+        import torch
+        p = self.params
+        if n_pairs is None:
+            n_pairs = prev.shape[0]
+        if pair_stride is None:
+            pair_stride = prev.stride(0) if prev.dim() == 3 else p.width * p.height
+        dev = prev.device
+        nb = self.nblocks(0)
+        if blocks is None:
+            blocks = torch.empty((n_pairs, nb), dtype=torch.int32, device=dev)
+        if flows is None:
+            flows = torch.empty((n_pairs, 16), dtype=torch.uint8, device=dev)
+        if subdirs is None and p.subpixel:
+            subdirs = torch.empty((n_pairs, nb), dtype=torch.uint8, device=dev)
+        L = workspace_layout(p, n_pairs)
+        if workspace is None:
+            if self._ws is None or self._ws.numel() < L.total_bytes or self._ws.device != dev:
+                self._ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
+            workspace = self._ws
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        self._check(lib.aof_flow_batch_device(
+            self._ctx, prev.data_ptr(), cur.data_ptr(), pair_stride, n_pairs, blocks.data_ptr(),
+            subdirs.data_ptr() if subdirs is not None else None, flows.data_ptr(),
+            workspace.data_ptr(), workspace.numel(), stream))
+        return blocks, flows, workspace
+
+    # -- host buffers -----------------------------------------------------------
+    def flow_pair_host(self, prev: np.ndarray, cur: np.ndarray):
+        p = self.params
+        prev = np.ascontiguousarray(prev, dtype=np.uint8)
+        cur = np.ascontiguousarray(cur, dtype=np.uint8)
+        assert prev.shape == cur.shape == (p.height, p.width)
+        nb = self.nblocks(0)
+        blocks = np.zeros(nb, dtype=BLOCK_DTYPE)
+        subdirs = np.zeros(nb, dtype=np.uint8)
+        flow = np.zeros(1, dtype=FLOW_DTYPE)
+        self._check(lib.aof_flow_pair_host(self._ctx, prev.ctypes.data, cur.ctypes.data,
+                                           blocks.ctypes.data, subdirs.ctypes.data,
+                                           flow.ctypes.data))
+        return blocks, subdirs, flow[0]
+
+    def stream_push(self, frame: np.ndarray):
+        """Returns None for the first frame, else the flow record vs the previous frame."""
+        p = self.params
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert frame.shape == (p.height, p.width)
+        flow = np.zeros(1, dtype=FLOW_DTYPE)
+        rc = self._check(lib.aof_stream_push_host(self._ctx, frame.ctypes.data, flow.ctypes.data))
+        return None if rc == 1 else flow[0]
+
+    def stream_reset(self):
+        self._check(lib.aof_stream_reset(self._ctx))
+
+
+def blocks_view(t) -> np.ndarray:
+    """int32 tensor/array of packed records -> structured numpy view."""
+    a = t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+    return np.ascontiguousarray(a).view(BLOCK_DTYPE).reshape(a.shape)
+
+
+def flows_view(t) -> np.ndarray:
+    a = t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+    return np.ascontiguousarray(a).view(FLOW_DTYPE).reshape(a.shape[0])
+
+
+DEFAULT_OUTPUT_RATE = 15
+DEFAULT_IMAGE_WIDTH = 64
+DEFAULT_IMAGE_HEIGHT = 64
+DEFAULT_SEARCH_SIZE = 4
+DEFAULT_FLOW_FEATURE_THRESHOLD = 30
+DEFAULT_FLOW_VALUE_THRESHOLD = 3000
+
+
+class OpticalFlowPX4:
+    """Python mirror of the facade class (facade/include/flow_px4.hpp): same
+    constructor arguments, ``calcFlow`` semantics and return convention as the
+    call site /root/reference/src/mainloop.cpp:322-331 expects -- negative
+    while integrating towards the output rate, else quality 0..255 with
+    ``dt_us`` and the angular flow (rad) filled in.  Compute runs in the HIP
+    engine through the C ABI's streaming entry point."""
+
+    def __init__(self, f_length_x, f_length_y, output_rate=DEFAULT_OUTPUT_RATE,
+                 img_width=DEFAULT_IMAGE_WIDTH, img_height=None,
+                 search_size=DEFAULT_SEARCH_SIZE,
+                 flow_feature_threshold=DEFAULT_FLOW_FEATURE_THRESHOLD,
+                 flow_value_threshold=DEFAULT_FLOW_VALUE_THRESHOLD, device=0, params=None):
+        if img_height is None:
+            img_height = img_width
+        self.focal_length_x = np.float32(f_length_x)
+        self.focal_length_y = np.float32(f_length_y)
+        self.output_rate = int(output_rate)
+        self.image_width, self.image_height = int(img_width), int(img_height)
+        if params is None:
+            params = px4flow_params(img_width, img_height, search_size, flow_feature_threshold,
+                                    flow_value_threshold)
+        self.engine = FlowEngine(params, device)
+        self._time_last_pub = 0
+        self._reset_rate()
+
+    def _reset_rate(self):
+        self._sum_x = np.float32(0)
+        self._sum_y = np.float32(0)
+        self._sum_q = 0
+        self._valid = 0
+
+    def getImageWidth(self):
+        return self.image_width
+
+    def getImageHeight(self):
+        return self.image_height
+
+    def calcFlow(self, img, img_time_us):
+        """Returns (quality, dt_us, flow_x_rad, flow_y_rad); quality < 0 means
+        'not ready, ignore the rest' exactly like the C++ out-parameters."""
+        f = self.engine.stream_push(np.asarray(img, dtype=np.uint8).reshape(
+            self.image_height, self.image_width))
+        if f is None:
+            return 0, 0, 0.0, 0.0
+        t = int(img_time_us) & 0xFFFFFFFF
+        q = int(f["quality"])
+        fx, fy = np.float32(f["flow_x"]), np.float32(f["flow_y"])
+        elapsed = (t - self._time_last_pub) & 0xFFFFFFFF
+        if self.output_rate <= 0:
+            dt = elapsed
+            self._time_last_pub = t
+        else:
+            if q > 0:
+                self._sum_x = np.float32(self._sum_x + fx)
+                self._sum_y = np.float32(self._sum_y + fy)
+                self._sum_q += q
+                self._valid += 1
+            if np.float32(elapsed) > np.float32(1.0e6) / np.float32(self.output_rate):
+                q = int(math.floor(np.float32(self._sum_q) / np.float32(self._valid))) \
+                    if self._valid > 0 else 0
+                fx, fy = self._sum_x, self._sum_y
+                self._reset_rate()
+                dt = elapsed
+                self._time_last_pub = t
+            else:
+                return -1, 0, 0.0, 0.0
+        dt_signed = dt - (1 << 32) if dt >= (1 << 31) else dt
+        return (q, dt_signed, float(np.arctan2(fx, self.focal_length_x, dtype=np.float32)),
+                float(np.arctan2(fy, self.focal_length_y, dtype=np.float32)))

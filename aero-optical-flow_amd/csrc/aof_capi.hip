@@ -1,0 +1,366 @@
+// Host side of the C ABI (include/aof.h): context, launch sequencing, the
+// host-buffer conveniences the C++ facade uses, and event-based kernel timing.
+//
+// Launch sequence of aof_flow_batch_device (DESIGN.md "Kernels"):
+//   1 level :                      K2 search(L0) -> K3 reduce
+//   + mean  : memset sums -> K1 -> K2 search(L0) -> K3 reduce
+//   2 levels: [memset] -> K1 -> K2 search(L1) -> K3 reduce(L1: predictor)
+//                              -> K2 search(L0, shifted by predictor) -> K3 reduce
+// Everything is enqueued on the caller's stream; nothing allocates or
+// synchronises, so the sequence can be captured into a hipGraph.
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "aof_internal.hpp"
+
+using namespace aof;
+
+struct aof_ctx {
+    aof_params params;
+    Grid g0, g1;
+    int device;
+    bool force_generic;
+    bool profiling;
+    const char *variant;
+    char err[256];
+    hipEvent_t ev[AOF_K_COUNT][2];
+    bool ev_valid[AOF_K_COUNT];
+    // host-convenience state (one pair)
+    hipStream_t stream;
+    uint8_t *d_frames[2];  // ping-pong: previous / current frame
+    int cur_slot;          // slot holding the newest frame
+    bool have_prev;
+    aof_block *d_blocks;
+    uint8_t *d_subdirs;
+    aof_flow *d_flow;
+    void *d_ws;
+    size_t ws_bytes;
+};
+
+namespace {
+
+int fail(aof_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(ctx, -EIO, "%s: %s", #expr, hipGetErrorString(e_));             \
+    } while (0)
+
+struct Timed {
+    aof_ctx *ctx; int id; hipStream_t s;
+    Timed(aof_ctx *c, int k, hipStream_t st) : ctx(c), id(k), s(st)
+    {
+        if (ctx->profiling) (void)hipEventRecord(ctx->ev[id][0], s);
+    }
+    ~Timed()
+    {
+        if (ctx->profiling) { (void)hipEventRecord(ctx->ev[id][1], s); ctx->ev_valid[id] = true; }
+    }
+};
+
+SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const uint8_t *cur,
+                       int64_t stride, aof_block *blocks, uint8_t *subdirs, const aof_flow *pred,
+                       const uint32_t *sums, int64_t n)
+{
+    const aof_params &p = ctx->params;
+    SearchArgs a;
+    a.prev = prev; a.cur = cur; a.pair_stride = stride;
+    a.w = p.width >> level; a.h = p.height >> level;
+    a.tile = p.tile; a.search = p.search;
+    a.grid = level ? ctx->g1 : ctx->g0;
+    a.feature_threshold = p.feature_threshold;
+    a.value_threshold = value_threshold_u16(p);
+    a.subpixel = p.subpixel;
+    a.blocks = blocks; a.subdirs = p.subpixel ? subdirs : nullptr;
+    a.pred = pred; a.sums = sums; a.level = level; a.n_pairs = n;
+    return a;
+}
+
+int run_search(aof_ctx *ctx, const SearchArgs &a, hipStream_t s)
+{
+    int rc;
+    if (!ctx->force_generic && tile8_supported(a)) rc = launch_search_tile8(a, s);
+    else rc = launch_search_generic(a, s);
+    if (rc) return fail(ctx, -EIO, "search launch: %s", hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aof_create(const aof_params *p, int device, aof_ctx **out)
+{
+    if (!out) return -EINVAL;
+    *out = nullptr;
+    int rc = aof_params_check(p);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -ENODEV;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return -ENODEV;  // kernels are gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return -ENODEV;
+
+    aof_ctx *ctx = new (std::nothrow) aof_ctx();
+    if (!ctx) return -ENOMEM;
+    std::memset(ctx, 0, sizeof(*ctx));
+    ctx->params = *p;
+    ctx->device = device;
+    grid_for_level(*p, 0, &ctx->g0);
+    if (p->pyramid_levels == 2) grid_for_level(*p, 1, &ctx->g1);
+    std::snprintf(ctx->err, sizeof(ctx->err), "ok");
+    for (int k = 0; k < AOF_K_COUNT; k++)
+        for (int e = 0; e < 2; e++)
+            if (hipEventCreate(&ctx->ev[k][e]) != hipSuccess) { aof_destroy(ctx); return -EIO; }
+
+    // which search kernel will level 0 use? (probe with aligned dummy pointers)
+    SearchArgs probe = search_args(ctx, 0, nullptr, nullptr, (int64_t)p->width * p->height, nullptr,
+                                   nullptr, nullptr, nullptr, 1);
+    ctx->variant = tile8_supported(probe) ? "tile8_lds" : "generic";
+    *out = ctx;
+    return 0;
+}
+
+void aof_destroy(aof_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (int k = 0; k < AOF_K_COUNT; k++)
+        for (int e = 0; e < 2; e++)
+            if (ctx->ev[k][e]) (void)hipEventDestroy(ctx->ev[k][e]);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    for (int i = 0; i < 2; i++) if (ctx->d_frames[i]) (void)hipFree(ctx->d_frames[i]);
+    if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
+    if (ctx->d_subdirs) (void)hipFree(ctx->d_subdirs);
+    if (ctx->d_flow) (void)hipFree(ctx->d_flow);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    delete ctx;
+}
+
+const char *aof_last_error(const aof_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int aof_get_params(const aof_ctx *ctx, aof_params *out)
+{
+    if (!ctx || !out) return -EINVAL;
+    *out = ctx->params;
+    return 0;
+}
+
+const char *aof_search_variant(const aof_ctx *ctx)
+{
+    if (!ctx) return "";
+    return ctx->force_generic ? "generic" : ctx->variant;
+}
+
+int aof_set_force_generic(aof_ctx *ctx, int on)
+{
+    if (!ctx) return -EINVAL;
+    ctx->force_generic = on != 0;
+    return 0;
+}
+
+int aof_set_profiling(aof_ctx *ctx, int on)
+{
+    if (!ctx) return -EINVAL;
+    ctx->profiling = on != 0;
+    for (int k = 0; k < AOF_K_COUNT; k++) ctx->ev_valid[k] = false;
+    return 0;
+}
+
+int aof_kernel_ms(aof_ctx *ctx, int kernel_id, float *ms)
+{
+    if (!ctx || !ms || kernel_id < 0 || kernel_id >= AOF_K_COUNT) return -EINVAL;
+    if (!ctx->ev_valid[kernel_id]) return fail(ctx, -EINVAL, "kernel %d was not timed", kernel_id);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[kernel_id][1]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev[kernel_id][0], ctx->ev[kernel_id][1]));
+    return 0;
+}
+
+int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_cur,
+                          int64_t pair_stride, int64_t n_pairs, aof_block *d_blocks,
+                          uint8_t *d_subdirs, aof_flow *d_flows, void *d_workspace,
+                          size_t workspace_bytes, void *stream)
+{
+    if (!ctx) return -EINVAL;
+    if (n_pairs < 0 || (n_pairs > 0 && (!d_prev || !d_cur || !d_flows)))
+        return fail(ctx, -EINVAL, "null frame or flow pointer");
+    if (n_pairs == 0) return 0;
+    const aof_params &p = ctx->params;
+    if (pair_stride < (int64_t)p.width * p.height && n_pairs > 1)
+        return fail(ctx, -EINVAL, "pair_stride smaller than a frame");
+    aof_ws_layout L;
+    int rc = aof_workspace_layout(&p, n_pairs, &L);
+    if (rc) return fail(ctx, rc, "bad workspace layout");
+    if (!d_workspace || workspace_bytes < L.total_bytes)
+        return fail(ctx, -ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, L.total_bytes);
+    if (reinterpret_cast<uintptr_t>(d_workspace) % 256)
+        return fail(ctx, -EINVAL, "workspace must be 256-byte aligned");
+
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint8_t *ws = static_cast<uint8_t *>(d_workspace);
+    const bool two = p.pyramid_levels == 2, eq = p.mean_subtract != 0;
+    uint32_t *sums = eq ? reinterpret_cast<uint32_t *>(ws + L.sums) : nullptr;
+    aof_block *blocks0 = d_blocks ? d_blocks : reinterpret_cast<aof_block *>(ws + L.l0_blocks);
+    uint8_t *subdirs0 = nullptr;
+    if (p.subpixel) subdirs0 = d_subdirs ? d_subdirs : ws + L.l0_subdirs;
+
+    if (eq) HIP_TRY(ctx, hipMemsetAsync(sums, 0, (size_t)n_pairs * 4 * sizeof(uint32_t), s));
+    if (two || eq) {
+        PyramidArgs a;
+        a.prev = d_prev; a.cur = d_cur; a.pair_stride = pair_stride;
+        a.w = p.width; a.h = p.height;
+        a.l1_prev = two ? ws + L.l1_prev : nullptr;
+        a.l1_cur = two ? ws + L.l1_cur : nullptr;
+        a.sums = sums; a.n_pairs = n_pairs;
+        Timed t(ctx, AOF_K_PYRAMID, s);
+        rc = launch_pyramid(a, s);
+        if (rc) return fail(ctx, -EIO, "pyramid launch: %s", hipGetErrorString((hipError_t)rc));
+    }
+    const aof_flow *pred = nullptr;
+    if (two) {
+        aof_block *blocks1 = reinterpret_cast<aof_block *>(ws + L.l1_blocks);
+        uint8_t *subdirs1 = p.subpixel ? ws + L.l1_subdirs : nullptr;
+        aof_flow *flows1 = reinterpret_cast<aof_flow *>(ws + L.l1_flows);
+        const int64_t l1_stride = (int64_t)(p.width / 2) * (p.height / 2);
+        {
+            SearchArgs a = search_args(ctx, 1, ws + L.l1_prev, ws + L.l1_cur, l1_stride, blocks1,
+                                       subdirs1, nullptr, sums, n_pairs);
+            Timed t(ctx, AOF_K_SEARCH_L1, s);
+            rc = run_search(ctx, a, s);
+            if (rc) return rc;
+        }
+        {
+            ReduceArgs r;
+            r.blocks = blocks1; r.subdirs = subdirs1; r.nblocks = ctx->g1.blocks();
+            r.range = level_range(p, 1); r.value_threshold = value_threshold_u16(p);
+            r.hist_filter = p.hist_filter; r.min_valid = p.min_valid;
+            r.flows = flows1; r.pred = nullptr; r.emit_predictor = 1; r.n_pairs = n_pairs;
+            Timed t(ctx, AOF_K_REDUCE_L1, s);
+            rc = launch_reduce(r, s);
+            if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));
+        }
+        pred = flows1;
+    }
+    {
+        SearchArgs a = search_args(ctx, 0, d_prev, d_cur, pair_stride, blocks0, subdirs0, pred, sums,
+                                   n_pairs);
+        Timed t(ctx, AOF_K_SEARCH, s);
+        rc = run_search(ctx, a, s);
+        if (rc) return rc;
+    }
+    {
+        ReduceArgs r;
+        r.blocks = blocks0; r.subdirs = subdirs0; r.nblocks = ctx->g0.blocks();
+        r.range = level_range(p, 0); r.value_threshold = value_threshold_u16(p);
+        r.hist_filter = p.hist_filter; r.min_valid = p.min_valid;
+        r.flows = d_flows; r.pred = pred; r.emit_predictor = 0; r.n_pairs = n_pairs;
+        Timed t(ctx, AOF_K_REDUCE, s);
+        rc = launch_reduce(r, s);
+        if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));
+    }
+    return 0;
+}
+
+// ---- host-buffer conveniences ------------------------------------------------
+
+static int ensure_host_state(aof_ctx *ctx)
+{
+    if (ctx->d_flow) return 0;
+    const aof_params &p = ctx->params;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t frame = (size_t)p.width * p.height;
+    aof_ws_layout L;
+    aof_workspace_layout(&p, 1, &L);
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_frames[i], frame));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_blocks, sizeof(aof_block) * (size_t)ctx->g0.blocks()));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_subdirs, (size_t)ctx->g0.blocks()));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_ws, L.total_bytes));
+    ctx->ws_bytes = L.total_bytes;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_flow, sizeof(aof_flow)));
+    return 0;
+}
+
+static int run_one(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_cur, aof_block *blocks,
+                   uint8_t *subdirs, aof_flow *flow)
+{
+    const aof_params &p = ctx->params;
+    int rc = aof_flow_batch_device(ctx, d_prev, d_cur, (int64_t)p.width * p.height, 1, ctx->d_blocks,
+                                   ctx->d_subdirs, ctx->d_flow, ctx->d_ws, ctx->ws_bytes,
+                                   ctx->stream);
+    if (rc) return rc;
+    const size_t nb = (size_t)ctx->g0.blocks();
+    HIP_TRY(ctx, hipMemcpyAsync(flow, ctx->d_flow, sizeof(aof_flow), hipMemcpyDeviceToHost, ctx->stream));
+    if (blocks)
+        HIP_TRY(ctx, hipMemcpyAsync(blocks, ctx->d_blocks, nb * sizeof(aof_block),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    if (subdirs) {
+        if (p.subpixel)
+            HIP_TRY(ctx, hipMemcpyAsync(subdirs, ctx->d_subdirs, nb, hipMemcpyDeviceToHost, ctx->stream));
+        else
+            std::memset(subdirs, 8, nb);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, aof_block *blocks,
+                       uint8_t *subdirs, aof_flow *flow)
+{
+    if (!ctx) return -EINVAL;
+    if (!prev || !cur || !flow) return fail(ctx, -EINVAL, "null frame or flow pointer");
+    int rc = ensure_host_state(ctx);
+    if (rc) return rc;
+    const size_t frame = (size_t)ctx->params.width * ctx->params.height;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[0], prev, frame, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[1], cur, frame, hipMemcpyHostToDevice, ctx->stream));
+    ctx->have_prev = false;  // the streaming state no longer describes a sequence
+    return run_one(ctx, ctx->d_frames[0], ctx->d_frames[1], blocks, subdirs, flow);
+}
+
+int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
+{
+    if (!ctx) return -EINVAL;
+    if (!frame || !flow) return fail(ctx, -EINVAL, "null frame or flow pointer");
+    int rc = ensure_host_state(ctx);
+    if (rc) return rc;
+    const size_t bytes = (size_t)ctx->params.width * ctx->params.height;
+    const int slot = ctx->have_prev ? 1 - ctx->cur_slot : 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[slot], frame, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->have_prev) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may free `frame` on return
+        ctx->cur_slot = slot;
+        ctx->have_prev = true;
+        std::memset(flow, 0, sizeof(*flow));
+        return 1;
+    }
+    rc = run_one(ctx, ctx->d_frames[ctx->cur_slot], ctx->d_frames[slot], nullptr, nullptr, flow);
+    ctx->cur_slot = slot;
+    return rc;
+}
+
+int aof_stream_reset(aof_ctx *ctx)
+{
+    if (!ctx) return -EINVAL;
+    ctx->have_prev = false;
+    return 0;
+}
+
+}  // extern "C"

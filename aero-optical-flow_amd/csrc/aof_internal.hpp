@@ -1,0 +1,80 @@
+// Internal declarations shared by the host side of the C ABI and the kernel
+// launchers.  Not installed; the public surface is include/aof.h.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include "aof.h"
+
+#if defined(__HIPCC__)
+#define AOF_HD __host__ __device__
+#else
+#define AOF_HD
+#endif
+
+namespace aof {
+
+struct Grid {
+    int32_t x0, y0, step_x, step_y, nx, ny;
+    AOF_HD int32_t blocks() const { return nx * ny; }
+};
+
+// Host-only parameter logic (aof_params.cpp).
+int grid_for_level(const aof_params &p, int level, Grid *g);
+int level_range(const aof_params &p, int level);  // histogram half-range R
+int value_threshold_u16(const aof_params &p);     // SAD gate clamped to the u16 record
+
+// Everything one search launch needs; passed to the kernels by value.
+struct SearchArgs {
+    const uint8_t *prev;       // level frames of the older image, pair i at +i*stride
+    const uint8_t *cur;        // level frames of the newer image
+    int64_t pair_stride;       // bytes between consecutive pairs (both arrays)
+    int32_t w, h;              // level frame size, row stride == w
+    int32_t tile, search;      // B, S
+    Grid grid;
+    int32_t feature_threshold;
+    int32_t value_threshold;   // clamped to <= 0xFFFF
+    int32_t subpixel;
+    aof_block *blocks;         // [n_pairs][grid.blocks()]
+    uint8_t *subdirs;          // [n_pairs][grid.blocks()] or nullptr
+    const aof_flow *pred;      // [n_pairs] level-1 results carrying the predictor, or nullptr
+    const uint32_t *sums;      // [n_pairs][2][2] pixel sums, or nullptr when not equalising
+    int32_t level;             // which sums column to use
+    int64_t n_pairs;
+};
+
+struct ReduceArgs {
+    const aof_block *blocks;
+    const uint8_t *subdirs;    // nullptr when half-pixel refinement is off
+    int32_t nblocks;
+    int32_t range;             // R
+    int32_t value_threshold;
+    int32_t hist_filter;
+    int32_t min_valid;
+    aof_flow *flows;           // [n_pairs]
+    const aof_flow *pred;      // copy pred_x/pred_y + PRED_VALID from here (level 0 of two), or nullptr
+    int32_t emit_predictor;    // level 1: write the integer predictor into pred_x/pred_y
+    int64_t n_pairs;
+};
+
+struct PyramidArgs {
+    const uint8_t *prev, *cur;
+    int64_t pair_stride;
+    int32_t w, h;
+    uint8_t *l1_prev, *l1_cur; // [n_pairs][h/2][w/2] or nullptr (sums only)
+    uint32_t *sums;            // [n_pairs][2][2] or nullptr (pyramid only)
+    int64_t n_pairs;
+};
+
+// Kernel launchers (one per .hip file).  All enqueue on `stream` and return the
+// hipError_t of the launch as int (0 = ok).
+int launch_pyramid(const PyramidArgs &a, void *stream);
+int launch_search_generic(const SearchArgs &a, void *stream);
+// LDS-tiled lane-per-block kernel for B=8, S=4 on a dense grid without
+// half-pixel refinement.  tile8_supported() says whether `a` qualifies.
+bool tile8_supported(const SearchArgs &a);
+int launch_search_tile8(const SearchArgs &a, void *stream);
+int launch_reduce(const ReduceArgs &a, void *stream);
+
+}  // namespace aof

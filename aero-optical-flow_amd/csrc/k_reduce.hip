@@ -1,0 +1,130 @@
+// K3 -- histogram-filtered flow reduction (DESIGN.md "Spec": Reduce).
+//
+// One workgroup per frame pair.  The block records (4 B each, just written by
+// K2 and still in L2) are read coalesced; accepted blocks vote into two
+// half-pixel shift histograms held in LDS (integer LDS atomics, so the result
+// does not depend on arrival order).  Lane 0 then applies the published
+// first-maximum peak search and the +-2-bin weighted mean, or the plain
+// average, and writes the 16-byte aof_flow.  The float arithmetic is a handful
+// of exactly-representable integers and two correctly-rounded divisions
+// (__fdiv_rn), so it is bit-identical to the host arithmetic of the oracle.
+#include "aof_device.hpp"
+#include "aof_internal.hpp"
+
+namespace aof {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxHist = 256;
+
+__device__ __forceinline__ void peak_window(int pos, int n, int *lo, int *hi)
+{
+    *lo = *hi = pos;
+    if (pos > 1 && pos < n - 2) { *lo = pos - 2; *hi = pos + 2; }
+    else if (pos == 0) { *hi = pos + 2; }
+    else if (pos == n - 1) { *lo = pos - 2; }
+    else if (pos == 1) { *lo = pos - 1; *hi = pos + 2; }
+    else if (pos == n - 2) { *lo = pos - 2; *hi = pos + 1; }
+}
+
+__device__ __forceinline__ long long floor_div(long long a, long long b)
+{
+    long long q = a / b;
+    if ((a % b) < 0) q--;
+    return q;
+}
+
+__global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
+{
+    __shared__ uint32_t hist[2][kMaxHist];
+    __shared__ int sums[3];  // sum2x, sum2y, count
+    const int64_t pair = blockIdx.x;
+    const int centre = 2 * a.range + 1, n = 2 * centre + 1;
+    for (int k = threadIdx.x; k < n; k += kThreads) { hist[0][k] = 0; hist[1][k] = 0; }
+    if (threadIdx.x < 3) sums[threadIdx.x] = 0;
+    __syncthreads();
+
+    const aof_block *blocks = a.blocks + pair * a.nblocks;
+    const uint8_t *subdirs = a.subdirs ? a.subdirs + pair * a.nblocks : nullptr;
+    int s2x = 0, s2y = 0, cnt = 0;
+    for (int b = threadIdx.x; b < a.nblocks; b += kThreads) {
+        const aof_block r = blocks[b];
+        if (r.sad == AOF_SAD_SKIPPED || (int)r.sad >= a.value_threshold) continue;
+        int hx = 0, hy = 0;
+        if (subdirs) {
+            const int sd = subdirs[b];
+            hx = (sd == 0 || sd == 1 || sd == 7) ? 1 : ((sd == 3 || sd == 4 || sd == 5) ? -1 : 0);
+            hy = (sd == 1 || sd == 2 || sd == 3) ? 1 : ((sd == 5 || sd == 6 || sd == 7) ? -1 : 0);
+        }
+        const int vx = 2 * r.dx + hx, vy = 2 * r.dy + hy;
+        atomicAdd(&hist[0][vx + centre], 1u);
+        atomicAdd(&hist[1][vy + centre], 1u);
+        s2x += vx; s2y += vy; cnt++;
+    }
+    atomicAdd(&sums[0], s2x);
+    atomicAdd(&sums[1], s2y);
+    atomicAdd(&sums[2], cnt);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    {
+#pragma clang fp contract(off)
+    aof_flow out;
+    out.flow_x = out.flow_y = 0.0f;
+    out.count = (uint32_t)sums[2];
+    out.quality = 0;
+    out.flags = 0;
+    out.pred_x = out.pred_y = 0;
+    int px = 0, py = 0;
+    const long long count = sums[2];
+    if (count > (long long)a.min_valid && count > 0) {
+        if (a.hist_filter) {
+            int posx = 0, posy = 0;
+            uint32_t maxx = 0, maxy = 0;
+            for (int k = 0; k < n; k++) {
+                if (hist[0][k] > maxx) { maxx = hist[0][k]; posx = k; }
+                if (hist[1][k] > maxy) { maxy = hist[1][k]; posy = k; }
+            }
+            int lo, hi;
+            uint32_t vx = 0, wx = 0, vy = 0, wy = 0;
+            peak_window(posx, n, &lo, &hi);
+            for (int k = lo; k <= hi; k++) { vx += (uint32_t)k * hist[0][k]; wx += hist[0][k]; }
+            peak_window(posy, n, &lo, &hi);
+            for (int k = lo; k <= hi; k++) { vy += (uint32_t)k * hist[1][k]; wy += hist[1][k]; }
+            out.flow_x = (__fdiv_rn((float)vx, (float)wx) - (float)centre) / 2.0f;
+            out.flow_y = (__fdiv_rn((float)vy, (float)wy) - (float)centre) / 2.0f;
+            px = (int)(floor_div(2ll * vx + wx, 2ll * wx) - centre);
+            py = (int)(floor_div(2ll * vy + wy, 2ll * wy) - centre);
+        } else {
+            out.flow_x = __fdiv_rn((float)sums[0] * 0.5f, (float)count);
+            out.flow_y = __fdiv_rn((float)sums[1] * 0.5f, (float)count);
+            px = (int)floor_div(2ll * sums[0] + count, 2ll * count);
+            py = (int)floor_div(2ll * sums[1] + count, 2ll * count);
+        }
+        out.quality = (uint8_t)((unsigned long long)count * 255ull / (unsigned long long)a.nblocks);
+        out.flags |= AOF_FLAG_FLOW_VALID;
+    }
+    if (a.emit_predictor) {
+        out.pred_x = (int8_t)px;
+        out.pred_y = (int8_t)py;
+    } else if (a.pred) {
+        const aof_flow p = a.pred[pair];
+        out.pred_x = p.pred_x;
+        out.pred_y = p.pred_y;
+        if (p.flags & AOF_FLAG_FLOW_VALID) out.flags |= AOF_FLAG_PRED_VALID;
+    }
+    a.flows[pair] = out;
+    }
+}
+
+}  // namespace
+
+int launch_reduce(const ReduceArgs &a, void *stream)
+{
+    if (a.n_pairs == 0) return 0;
+    hipLaunchKernelGGL(k_reduce, dim3((uint32_t)a.n_pairs), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace aof

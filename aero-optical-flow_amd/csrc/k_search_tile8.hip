@@ -1,0 +1,235 @@
+// K2 (tile8) -- the dominant kernel: 8x8 SAD search over +-4 px on a dense grid
+// (DESIGN.md "Spec": Search; "Kernels": K2).
+//
+// Mapping.  A workgroup owns a strip of `rb` block rows of one frame pair and
+// stages the strip's pixels ONCE into LDS as two flat, fully coalesced 16-byte
+// copies (rows are contiguous in HBM because stride == width):
+//     cur  rows [8*by0 + py, +8*rows+8)   -> smem[0 ..)
+//     prev rows [8*by0 + 4,  +8*rows)     -> smem[cur_bytes ..)
+// Each LANE then owns one whole block: it keeps the 8x8 reference tile in 16
+// VGPRs, streams the 16 search rows out of LDS and evaluates all 81 candidates
+// with v_qsad_pk_u16_u8 -- four horizontally sliding 4-byte SADs per
+// instruction, packed u16 accumulators (max 64*255 = 16320 fits) -- plus
+// v_sad_hi_u8 for the ninth column, which accumulates straight into the high
+// half of a register pre-loaded with the candidate index.  No cross-lane
+// traffic at all: the arg-min is a per-lane v_min3_u32 tree over the packed
+// keys (sad << 16 | idx), i.e. "first minimum in scan order wins".
+//
+// With the dense grid origin at S = 4 and step 8 every search window starts on
+// an 8-byte boundary, so the unshifted variant reads LDS with ds_read_b64 and
+// needs no byte realignment.  The SHIFTED variant (level 0 of the 2-level
+// pyramid, window displaced by the per-pair predictor) reads five dwords per
+// row and realigns with v_alignbyte_b32 by the wave-uniform (px & 3).
+#include "aof_device.hpp"
+#include "aof_internal.hpp"
+
+namespace aof {
+
+namespace {
+
+constexpr int kMaxThreads = 512;
+constexpr int kLdsBudget = 64 * 1024;
+
+__device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
+{
+    return __builtin_amdgcn_qsad_pk_u16_u8(window, ref, acc);
+}
+__device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | lo; }
+
+template <bool SHIFTED>
+__global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int rb, int nstrips,
+                                                              uint32_t total_wgs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const uint32_t logical = xcd_remap(blockIdx.x, total_wgs);
+    const int strip = (int)(logical % (uint32_t)nstrips);
+    const int64_t pair = (int64_t)(logical / (uint32_t)nstrips);
+    const int W = a.w, H = a.h, nx = a.grid.nx, ny = a.grid.ny;
+    const int by0 = strip * rb;
+    const int rows = min(rb, ny - by0);
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+
+    int px = 0, py = 0;
+    if (SHIFTED) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
+    const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * H));
+
+    // ---- stage the strip into LDS (flat 16-byte copies) ----
+    const int n_cur_rows = 8 * rows + 8;
+    const int yc0 = 8 * by0 + py;                 // frame row of LDS cur row 0
+    const int r_lo = max(0, -yc0);                // valid LDS cur rows [r_lo, r_hi)
+    const int r_hi = min(n_cur_rows, H - yc0);
+    uint8_t *s_cur = smem;
+    uint8_t *s_prev = smem + (size_t)(8 * rb + 8) * W;
+    const uint8_t *g_cur = a.cur + pair * a.pair_stride + (int64_t)(yc0 + r_lo) * W;
+    const uint8_t *g_prev = a.prev + pair * a.pair_stride + (int64_t)(8 * by0 + 4) * W;
+    const int cur_chunks = r_hi > r_lo ? (r_hi - r_lo) * (W / 16) : 0;
+    const int prev_chunks = 8 * rows * (W / 16);
+    if (delta == 0) {
+        for (int c = tid; c < cur_chunks; c += nthreads)
+            *reinterpret_cast<uint4 *>(s_cur + (size_t)r_lo * W + (size_t)c * 16) =
+                *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
+    } else {
+        for (int c = tid; c < cur_chunks; c += nthreads) {
+            uint4 v = *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
+            v.x = sat_add_u8x4(v.x, delta); v.y = sat_add_u8x4(v.y, delta);
+            v.z = sat_add_u8x4(v.z, delta); v.w = sat_add_u8x4(v.w, delta);
+            *reinterpret_cast<uint4 *>(s_cur + (size_t)r_lo * W + (size_t)c * 16) = v;
+        }
+    }
+    for (int c = tid; c < prev_chunks; c += nthreads)
+        *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) =
+            *reinterpret_cast<const uint4 *>(g_prev + (size_t)c * 16);
+    __syncthreads();
+
+    // ---- one block per lane ----
+    if (tid >= rows * nx) return;
+    const int brow = tid / nx, bx = tid % nx;
+    bool inside = true;
+    int xs = 8 * bx;                              // LDS byte column of the window start
+    if (SHIFTED) {
+        xs += px;
+        inside = xs >= 0 && xs + 16 <= W && 8 * brow >= r_lo && 8 * brow + 16 <= r_hi;
+        if (!inside) xs = 0;                      // keep the (ignored) reads in range
+    }
+
+    // reference tile: 8 rows x 2 dwords, frame column 8*bx + 4
+    uint32_t ref[8][2];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t *p =
+            reinterpret_cast<const uint32_t *>(s_prev + (size_t)(8 * brow + r) * W + 8 * bx + 4);
+        ref[r][0] = p[0];
+        ref[r][1] = p[1];
+    }
+
+    // 4x4 gradient gate on tile bytes [2..5] x rows [2..5]
+    uint32_t diff = 0;
+    {
+        uint32_t mid[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            mid[r] = __builtin_amdgcn_alignbyte(ref[r + 2][1], ref[r + 2][0], 2);  // bytes 2..5
+#pragma unroll
+        for (int r = 0; r < 3; r++) diff = __builtin_amdgcn_sad_u8(mid[r], mid[r + 1], diff);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            // bytes (3,4,5,5) against (2,3,4,5): the doubled last byte adds |p5-p5| = 0
+            const uint32_t sh = __builtin_amdgcn_perm(0u, mid[r], 0x03030201u);
+            diff = __builtin_amdgcn_sad_u8(mid[r], sh, diff);
+        }
+    }
+
+    // accumulators: per dy, offsets 0..3 / 4..7 packed u16, offset 8 as (sad<<16 | idx)
+    u64 acc_lo[9], acc_hi[9];
+    uint32_t acc_8[9];
+#pragma unroll
+    for (int d = 0; d < 9; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)(d * 9 + 8); }
+
+    const int sh = SHIFTED ? (px & 3) : 0;
+    const uint8_t *win = s_cur + (size_t)(8 * brow) * W + (SHIFTED ? (xs & ~3) : xs);
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        uint32_t w0, w1, w2, w3;
+        if (SHIFTED) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(win + (size_t)s * W);
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+            w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            w3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+        } else {
+            const uint2 *p = reinterpret_cast<const uint2 *>(win + (size_t)s * W);
+            const uint2 a0 = p[0], a1 = p[1];
+            w0 = a0.x; w1 = a0.y; w2 = a1.x; w3 = a1.y;
+        }
+        const u64 p01 = pack64(w0, w1), p12 = pack64(w1, w2), p23 = pack64(w2, w3);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int d = s - r;  // dy index 0..8 (dy = d - 4)
+            if (d < 0 || d > 8) continue;
+            acc_lo[d] = qsad(p01, ref[r][0], acc_lo[d]);
+            acc_lo[d] = qsad(p12, ref[r][1], acc_lo[d]);
+            acc_hi[d] = qsad(p12, ref[r][0], acc_hi[d]);
+            acc_hi[d] = qsad(p23, ref[r][1], acc_hi[d]);
+            acc_8[d] = __builtin_amdgcn_sad_hi_u8(w2, ref[r][0], acc_8[d]);
+            acc_8[d] = __builtin_amdgcn_sad_hi_u8(w3, ref[r][1], acc_8[d]);
+        }
+    }
+
+    // arg-min over the 81 packed keys, scan order = key order
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 0; d < 9; d++) {
+        const uint32_t base = (uint32_t)(d * 9);
+        const uint32_t l0 = (uint32_t)acc_lo[d], l1 = (uint32_t)(acc_lo[d] >> 32);
+        const uint32_t h0 = (uint32_t)acc_hi[d], h1 = (uint32_t)(acc_hi[d] >> 32);
+        const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
+        const uint32_t k2 = (l1 << 16) | (base + 2), k3 = (l1 & 0xFFFF0000u) | (base + 3);
+        const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
+        const uint32_t k6 = (h1 << 16) | (base + 6), k7 = (h1 & 0xFFFF0000u) | (base + 7);
+        best = min(best, min(min(k0, k1), k2));
+        best = min(best, min(min(k3, k4), k5));
+        best = min(best, min(min(k6, k7), acc_8[d]));
+    }
+
+    aof_block rec;
+    rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
+    if (inside && diff >= (uint32_t)a.feature_threshold) {
+        const int idx = (int)(best & 0xFFFFu);
+        rec.dx = (int8_t)(px + idx % 9 - 4);
+        rec.dy = (int8_t)(py + idx / 9 - 4);
+        rec.sad = (uint16_t)(best >> 16);
+    }
+    a.blocks[pair * (int64_t)(nx * ny) + (int64_t)(by0 + brow) * nx + bx] = rec;
+}
+
+struct Tile8Plan { int rb, threads, nstrips; size_t lds; };
+
+Tile8Plan plan_tile8(const SearchArgs &a)
+{
+    // Pick the strip height that keeps most lanes busy over the whole frame.
+    Tile8Plan best = {0, 0, 0, 0};
+    double best_eff = -1.0;
+    for (int rb = 1; rb <= 16; rb++) {
+        const int items = rb * a.grid.nx;
+        const int threads = (items + 63) / 64 * 64;
+        const size_t lds = (size_t)(16 * rb + 8) * a.w + 16;
+        if (threads > kMaxThreads || lds > (size_t)kLdsBudget) break;
+        const int nstrips = (a.grid.ny + rb - 1) / rb;
+        const double eff = (double)a.grid.blocks() / ((double)nstrips * threads);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = {rb, threads, nstrips, lds}; }
+    }
+    return best;
+}
+
+}  // namespace
+
+bool tile8_supported(const SearchArgs &a)
+{
+    if (a.tile != 8 || a.search != 4 || a.subpixel) return false;
+    if (a.grid.x0 != 4 || a.grid.y0 != 4 || a.grid.step_x != 8 || a.grid.step_y != 8) return false;
+    if (a.w % 16 || a.pair_stride % 16) return false;
+    if (reinterpret_cast<uintptr_t>(a.prev) % 16 || reinterpret_cast<uintptr_t>(a.cur) % 16) return false;
+    if ((int64_t)a.w * a.h > 0x7FFFFFFF) return false;
+    return plan_tile8(a).rb > 0;
+}
+
+int launch_search_tile8(const SearchArgs &a, void *stream)
+{
+    if (a.n_pairs == 0) return 0;
+    const Tile8Plan p = plan_tile8(a);
+    if (p.rb == 0) return (int)hipErrorInvalidValue;
+    const int64_t total = a.n_pairs * p.nstrips;
+    if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.pred)
+        hipLaunchKernelGGL(k_search_tile8<true>, dim3((uint32_t)total), dim3(p.threads), p.lds, s, a,
+                           p.rb, p.nstrips, (uint32_t)total);
+    else
+        hipLaunchKernelGGL(k_search_tile8<false>, dim3((uint32_t)total), dim3(p.threads), p.lds, s,
+                           a, p.rb, p.nstrips, (uint32_t)total);
+    return (int)hipGetLastError();
+}
+
+}  // namespace aof

@@ -1,0 +1,157 @@
+/*
+ * aof.h -- C ABI of the MI355X-native sparse SAD block-matching flow engine.
+ *
+ * This is the drop-in boundary for the one hot path of
+ * intel-aero/aero-optical-flow: the frame-to-frame flow estimate that
+ * Mainloop::camera_callback() obtains from the PX4 OpticalFlow submodule via
+ *     _optical_flow->calcFlow(img, t_us, dt_us, flow_x, flow_y)
+ * (/root/reference/src/mainloop.cpp:322; constructor :423-424; getters
+ * :295-297; negative-return gate :327-331).  The reference binds that path as
+ * a C++ class (header <flow_opencv.hpp>, /root/reference/src/mainloop.h:36);
+ * the C++ facade in aero-optical-flow_amd/facade re-exports those classes on
+ * top of this ABI, and INTEGRATION.md shows the CMake hook that replaces
+ * modules/OpticalFlow (/root/reference/CMakeLists.txt:10,17).
+ *
+ * Conventions: plain C types, caller owns every buffer, no exceptions cross
+ * the boundary.  Functions return 0 on success or a negative errno-style code;
+ * aof_last_error() gives the text.  A context is thread-compatible (one
+ * caller at a time), which is what the reference guarantees: calcFlow is only
+ * called under _mainloop_lock (/root/reference/src/mainloop.cpp:283).
+ *
+ * There is NO CPU fallback: every entry point that computes flow runs the HIP
+ * kernels on a gfx950 device and fails (-ENODEV) when none is present.
+ */
+#ifndef AOF_H
+#define AOF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOF_VERSION 100 /* 0.1.0 */
+
+#define AOF_GRID_DENSE 0   /* origin = margin, step = tile */
+#define AOF_GRID_PX4FLOW 1 /* published sparse grid: num_blocks tiles per axis */
+
+/* Algorithm parameters (DESIGN.md "Spec").  aof_params_default() gives the
+ * configuration BASELINE.json quotes the metric on. */
+typedef struct aof_params {
+    int32_t width, height;     /* level-0 frame, 8-bit grey, row stride == width
+                                  (the caller makes it contiguous, mainloop.cpp:317-320) */
+    int32_t tile;              /* B: 8 or 16 */
+    int32_t search;            /* S: 1..8 */
+    int32_t grid_mode;         /* AOF_GRID_* */
+    int32_t num_blocks;        /* AOF_GRID_PX4FLOW only */
+    int32_t feature_threshold; /* 4x4 gradient gate */
+    int32_t value_threshold;   /* SAD acceptance gate */
+    int32_t subpixel;          /* half-pixel refinement */
+    int32_t hist_filter;       /* 1: histogram peak filter, 0: plain average */
+    int32_t pyramid_levels;    /* 1 or 2 */
+    int32_t mean_subtract;     /* equalise cur to prev frame mean per level */
+    int32_t min_valid;         /* flow valid iff accepted blocks > min_valid */
+} aof_params;
+
+/* Per-block record, 4 bytes: integer shift of the best match and its SAD.
+ * sad == 0xFFFF marks a skipped block (gradient gate / window outside frame). */
+typedef struct aof_block {
+    int8_t dx, dy;
+    uint16_t sad;
+} aof_block;
+
+#define AOF_SAD_SKIPPED 0xFFFFu
+#define AOF_FLAG_FLOW_VALID 1u
+#define AOF_FLAG_PRED_VALID 2u
+
+/* Per-pair result, 16 bytes. */
+typedef struct aof_flow {
+    float flow_x, flow_y; /* level-0 pixels */
+    uint32_t count;       /* accepted blocks */
+    uint8_t quality;      /* count*255/blocks, 0 when flow invalid (mainloop.cpp:371) */
+    uint8_t flags;        /* AOF_FLAG_* */
+    int8_t pred_x, pred_y;/* level-1 predictor, level-0 pixels */
+} aof_flow;
+
+/* Byte offsets of the intermediates inside the caller's workspace (tests and
+ * tools read them; the layout is fixed by aof_workspace_layout()). */
+typedef struct aof_ws_layout {
+    size_t total_bytes;
+    size_t sums;      /* uint32 [n_pairs][2 frames: prev,cur][2 levels] pixel sums */
+    size_t l1_prev;   /* u8 [n_pairs][h/2][w/2] */
+    size_t l1_cur;    /* u8 [n_pairs][h/2][w/2] */
+    size_t l1_blocks; /* aof_block [n_pairs][nb1] */
+    size_t l1_subdirs;/* u8 [n_pairs][nb1] */
+    size_t l1_flows;  /* aof_flow [n_pairs] (pred_x/pred_y = predictor) */
+    size_t l0_blocks; /* aof_block [n_pairs][nb0] when the caller passes none */
+    size_t l0_subdirs;/* u8 [n_pairs][nb0] when the caller passes none */
+} aof_ws_layout;
+
+typedef struct aof_ctx aof_ctx;
+
+/* Kernel ids for aof_kernel_ms(). */
+#define AOF_K_PYRAMID 0 /* K1: frame sums + 2x2 pyramid */
+#define AOF_K_SEARCH_L1 1
+#define AOF_K_REDUCE_L1 2
+#define AOF_K_SEARCH 3  /* K2: SAD search, level 0 -- the dominant kernel */
+#define AOF_K_REDUCE 4  /* K3: histogram-filtered flow reduction */
+#define AOF_K_COUNT 5
+
+int aof_version(void);
+const char *aof_strerror(int code);
+
+/* ---- parameters (host only, no GPU needed) ---- */
+int aof_params_default(aof_params *p, int width, int height);
+/* Published PX4Flow configuration: sparse grid, half-pixel refinement. */
+int aof_params_px4flow(aof_params *p, int width, int height, int search,
+                       int feature_threshold, int value_threshold);
+int aof_params_check(const aof_params *p);
+/* Block grid of a pyramid level: origin, step, counts. */
+int aof_grid(const aof_params *p, int level, int32_t *x0, int32_t *y0, int32_t *step_x,
+             int32_t *step_y, int32_t *nx, int32_t *ny);
+int aof_workspace_layout(const aof_params *p, int64_t n_pairs, aof_ws_layout *out);
+
+/* ---- context ---- */
+/* device: HIP device ordinal.  Fails with -ENODEV when no gfx950 GPU is usable. */
+int aof_create(const aof_params *p, int device, aof_ctx **out);
+void aof_destroy(aof_ctx *ctx);
+const char *aof_last_error(const aof_ctx *ctx);
+int aof_get_params(const aof_ctx *ctx, aof_params *out);
+/* Name of the search kernel variant the context selected ("tile8_lds", "generic", ...). */
+const char *aof_search_variant(const aof_ctx *ctx);
+/* Force the generic search kernel (tests compare the two device paths). */
+int aof_set_force_generic(aof_ctx *ctx, int on);
+
+/* ---- the hot path, device-resident (batched) ----
+ * d_prev/d_cur: device pointers, pair i at +i*pair_stride bytes, each frame
+ * width*height bytes.  For a frame SEQUENCE pass d_cur = d_prev + width*height
+ * and pair_stride = width*height.
+ * d_blocks: [n_pairs][nb0] records or NULL.  d_subdirs: [n_pairs][nb0] or NULL.
+ * d_flows: [n_pairs], required.  d_workspace: >= aof_workspace_layout().total_bytes,
+ * 256-byte aligned.  stream: hipStream_t (NULL = default stream).
+ * Asynchronous: returns after enqueueing; no allocation, no host sync. */
+int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_cur,
+                          int64_t pair_stride, int64_t n_pairs, aof_block *d_blocks,
+                          uint8_t *d_subdirs, aof_flow *d_flows, void *d_workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* ---- host-buffer conveniences (what the C++ facade calls) ----
+ * Synchronous: copy in, run the kernels above, copy out.  blocks/subdirs may be NULL. */
+int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, aof_block *blocks,
+                       uint8_t *subdirs, aof_flow *flow);
+/* Streaming: the context keeps the previous frame on the device.  Returns 1 for
+ * the first frame after create/reset (nothing to compare, *flow zeroed), 0 afterwards. */
+int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow);
+int aof_stream_reset(aof_ctx *ctx);
+
+/* ---- measurement ----
+ * With profiling on, every launch is bracketed by HIP events on its stream;
+ * aof_kernel_ms() synchronises on them and returns the last launch's duration. */
+int aof_set_profiling(aof_ctx *ctx, int on);
+int aof_kernel_ms(aof_ctx *ctx, int kernel_id, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
