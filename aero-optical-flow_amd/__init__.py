@@ -16,7 +16,6 @@ The directory name contains a hyphen, so import it through
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 
 import numpy as np
@@ -89,6 +88,8 @@ def _load():
         "aof_stream_reset": (C.c_int, [VP]),
         "aof_set_profiling": (C.c_int, [VP, C.c_int]),
         "aof_kernel_ms": (C.c_int, [VP, C.c_int, P(C.c_float)]),
+        "aof_profile_count": (C.c_int, [VP, C.c_int]),
+        "aof_profile_ms": (C.c_int, [VP, C.c_int, C.c_int, P(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -191,6 +192,17 @@ class FlowEngine:
         self._check(lib.aof_kernel_ms(self._ctx, kernel_id, C.byref(ms)))
         return ms.value
 
+    def profile_ms(self, kernel_id):
+        """Durations (ms) of the launches of one kernel timed since profiling was enabled
+        (at most the last AOF_PROFILE_RING); synchronises on their events."""
+        n = self._check(lib.aof_profile_count(self._ctx, kernel_id))
+        out = []
+        ms = C.c_float()
+        for i in range(n):
+            self._check(lib.aof_profile_ms(self._ctx, kernel_id, i, C.byref(ms)))
+            out.append(ms.value)
+        return out
+
     def grid(self, level=0):
         return grid(self.params, level)
 
@@ -269,6 +281,34 @@ def flows_view(t) -> np.ndarray:
     return np.ascontiguousarray(a).view(FLOW_DTYPE).reshape(a.shape[0])
 
 
+# ---- the C++ facade (facade/libOpticalFlow.so) through its plain-C handles -------
+
+FACADE_PATH = os.path.join(_HERE, "facade", "libOpticalFlow.so")
+_facade = None
+
+
+def facade_lib():
+    """facade/libOpticalFlow.so: the drop-in classes OpticalFlowPX4 / OpticalFlowOpenCV."""
+    global _facade
+    if _facade is None:
+        if not os.path.exists(FACADE_PATH):
+            raise ImportError(f"{FACADE_PATH} is missing: run __graft_entry__.build()")
+        f = C.CDLL(FACADE_PATH)
+        f.aof_facade_px4_create.restype = C.c_void_p
+        f.aof_facade_px4_create.argtypes = [C.c_float, C.c_float] + [C.c_int] * 6
+        f.aof_facade_opencv_create.restype = C.c_void_p
+        f.aof_facade_opencv_create.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]
+        f.aof_facade_destroy.argtypes = [C.c_void_p]
+        f.aof_facade_calc_flow.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int),
+                                           C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        f.aof_facade_image_width.argtypes = [C.c_void_p]
+        f.aof_facade_image_height.argtypes = [C.c_void_p]
+        f.aof_facade_last_error.restype = C.c_char_p
+        f.aof_facade_last_error.argtypes = [C.c_void_p]
+        _facade = f
+    return _facade
+
+
 DEFAULT_OUTPUT_RATE = 15
 DEFAULT_IMAGE_WIDTH = 64
 DEFAULT_IMAGE_HEIGHT = 64
@@ -277,73 +317,57 @@ DEFAULT_FLOW_FEATURE_THRESHOLD = 30
 DEFAULT_FLOW_VALUE_THRESHOLD = 3000
 
 
-class OpticalFlowPX4:
-    """Python mirror of the facade class (facade/include/flow_px4.hpp): same
-    constructor arguments, ``calcFlow`` semantics and return convention as the
-    call site /root/reference/src/mainloop.cpp:322-331 expects -- negative
-    while integrating towards the output rate, else quality 0..255 with
-    ``dt_us`` and the angular flow (rad) filled in.  Compute runs in the HIP
-    engine through the C ABI's streaming entry point."""
-
-    def __init__(self, f_length_x, f_length_y, output_rate=DEFAULT_OUTPUT_RATE,
-                 img_width=DEFAULT_IMAGE_WIDTH, img_height=None,
-                 search_size=DEFAULT_SEARCH_SIZE,
-                 flow_feature_threshold=DEFAULT_FLOW_FEATURE_THRESHOLD,
-                 flow_value_threshold=DEFAULT_FLOW_VALUE_THRESHOLD, device=0, params=None):
-        if img_height is None:
-            img_height = img_width
-        self.focal_length_x = np.float32(f_length_x)
-        self.focal_length_y = np.float32(f_length_y)
-        self.output_rate = int(output_rate)
-        self.image_width, self.image_height = int(img_width), int(img_height)
-        if params is None:
-            params = px4flow_params(img_width, img_height, search_size, flow_feature_threshold,
-                                    flow_value_threshold)
-        self.engine = FlowEngine(params, device)
-        self._time_last_pub = 0
-        self._reset_rate()
-
-    def _reset_rate(self):
-        self._sum_x = np.float32(0)
-        self._sum_y = np.float32(0)
-        self._sum_q = 0
-        self._valid = 0
+class _FacadeFlow:
+    """Handle on one C++ facade object.  ``calcFlow`` keeps the reference's
+    convention (/root/reference/src/mainloop.cpp:322-331): the return value is
+    negative while the engine integrates towards its output rate, else the
+    quality 0..255 with dt_us and the angular flow (rad)."""
+    _h = None
 
     def getImageWidth(self):
-        return self.image_width
+        return facade_lib().aof_facade_image_width(self._h)
 
     def getImageHeight(self):
-        return self.image_height
+        return facade_lib().aof_facade_image_height(self._h)
+
+    def lastError(self):
+        return facade_lib().aof_facade_last_error(self._h).decode()
 
     def calcFlow(self, img, img_time_us):
-        """Returns (quality, dt_us, flow_x_rad, flow_y_rad); quality < 0 means
-        'not ready, ignore the rest' exactly like the C++ out-parameters."""
-        f = self.engine.stream_push(np.asarray(img, dtype=np.uint8).reshape(
-            self.image_height, self.image_width))
-        if f is None:
-            return 0, 0, 0.0, 0.0
-        t = int(img_time_us) & 0xFFFFFFFF
-        q = int(f["quality"])
-        fx, fy = np.float32(f["flow_x"]), np.float32(f["flow_y"])
-        elapsed = (t - self._time_last_pub) & 0xFFFFFFFF
-        if self.output_rate <= 0:
-            dt = elapsed
-            self._time_last_pub = t
-        else:
-            if q > 0:
-                self._sum_x = np.float32(self._sum_x + fx)
-                self._sum_y = np.float32(self._sum_y + fy)
-                self._sum_q += q
-                self._valid += 1
-            if np.float32(elapsed) > np.float32(1.0e6) / np.float32(self.output_rate):
-                q = int(math.floor(np.float32(self._sum_q) / np.float32(self._valid))) \
-                    if self._valid > 0 else 0
-                fx, fy = self._sum_x, self._sum_y
-                self._reset_rate()
-                dt = elapsed
-                self._time_last_pub = t
-            else:
-                return -1, 0, 0.0, 0.0
-        dt_signed = dt - (1 << 32) if dt >= (1 << 31) else dt
-        return (q, dt_signed, float(np.arctan2(fx, self.focal_length_x, dtype=np.float32)),
-                float(np.arctan2(fy, self.focal_length_y, dtype=np.float32)))
+        """Returns (quality, dt_us, flow_x_rad, flow_y_rad); the C++ out-parameters keep
+        their previous values (0 here) when the call does not publish."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        assert img.size == self.getImageWidth() * self.getImageHeight()
+        dt, fx, fy = C.c_int(0), C.c_float(0), C.c_float(0)
+        q = facade_lib().aof_facade_calc_flow(self._h, img.ctypes.data, int(img_time_us) & 0xFFFFFFFF,
+                                              C.byref(dt), C.byref(fx), C.byref(fy))
+        return q, dt.value, fx.value, fy.value
+
+    def close(self):
+        if self._h:
+            facade_lib().aof_facade_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class OpticalFlowPX4(_FacadeFlow):
+    """facade/include/flow_px4.hpp"""
+
+    def __init__(self, f_length_x, f_length_y, output_rate=DEFAULT_OUTPUT_RATE,
+                 img_width=DEFAULT_IMAGE_WIDTH, img_height=DEFAULT_IMAGE_HEIGHT,
+                 search_size=DEFAULT_SEARCH_SIZE,
+                 flow_feature_threshold=DEFAULT_FLOW_FEATURE_THRESHOLD,
+                 flow_value_threshold=DEFAULT_FLOW_VALUE_THRESHOLD):
+        self._h = facade_lib().aof_facade_px4_create(f_length_x, f_length_y, output_rate, img_width,
+                                                      img_height, search_size,
+                                                      flow_feature_threshold, flow_value_threshold)
+
+
+class OpticalFlowOpenCV(_FacadeFlow):
+    """facade/include/flow_opencv.hpp -- the class /root/reference/src/mainloop.cpp:423 creates."""
+
+    def __init__(self, f_length_x, f_length_y, output_rate=DEFAULT_OUTPUT_RATE,
+                 img_width=DEFAULT_IMAGE_WIDTH, img_height=DEFAULT_IMAGE_HEIGHT):
+        self._h = facade_lib().aof_facade_opencv_create(f_length_x, f_length_y, output_rate,
+                                                         img_width, img_height)

@@ -28,8 +28,8 @@ struct aof_ctx {
     bool profiling;
     const char *variant;
     char err[256];
-    hipEvent_t ev[AOF_K_COUNT][2];
-    bool ev_valid[AOF_K_COUNT];
+    hipEvent_t (*ev)[AOF_PROFILE_RING][2];  // [AOF_K_COUNT][ring][start,stop], created on demand
+    int64_t ev_count[AOF_K_COUNT];           // launches timed since profiling was switched on
     // host-convenience state (one pair)
     hipStream_t stream;
     uint8_t *d_frames[2];  // ping-pong: previous / current frame
@@ -63,14 +63,18 @@ int fail(aof_ctx *ctx, int code, const char *fmt, ...)
     } while (0)
 
 struct Timed {
-    aof_ctx *ctx; int id; hipStream_t s;
-    Timed(aof_ctx *c, int k, hipStream_t st) : ctx(c), id(k), s(st)
+    aof_ctx *ctx; int id; hipStream_t s; int slot;
+    Timed(aof_ctx *c, int k, hipStream_t st) : ctx(c), id(k), s(st), slot(0)
     {
-        if (ctx->profiling) (void)hipEventRecord(ctx->ev[id][0], s);
+        if (!ctx->profiling) return;
+        slot = (int)(ctx->ev_count[id] % AOF_PROFILE_RING);
+        (void)hipEventRecord(ctx->ev[id][slot][0], s);
     }
     ~Timed()
     {
-        if (ctx->profiling) { (void)hipEventRecord(ctx->ev[id][1], s); ctx->ev_valid[id] = true; }
+        if (!ctx->profiling) return;
+        (void)hipEventRecord(ctx->ev[id][slot][1], s);
+        ctx->ev_count[id]++;
     }
 };
 
@@ -126,9 +130,6 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
     grid_for_level(*p, 0, &ctx->g0);
     if (p->pyramid_levels == 2) grid_for_level(*p, 1, &ctx->g1);
     std::snprintf(ctx->err, sizeof(ctx->err), "ok");
-    for (int k = 0; k < AOF_K_COUNT; k++)
-        for (int e = 0; e < 2; e++)
-            if (hipEventCreate(&ctx->ev[k][e]) != hipSuccess) { aof_destroy(ctx); return -EIO; }
 
     // which search kernel will level 0 use? (probe with aligned dummy pointers)
     SearchArgs probe = search_args(ctx, 0, nullptr, nullptr, (int64_t)p->width * p->height, nullptr,
@@ -142,9 +143,13 @@ void aof_destroy(aof_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (int k = 0; k < AOF_K_COUNT; k++)
-        for (int e = 0; e < 2; e++)
-            if (ctx->ev[k][e]) (void)hipEventDestroy(ctx->ev[k][e]);
+    if (ctx->ev) {
+        for (int k = 0; k < AOF_K_COUNT; k++)
+            for (int r = 0; r < AOF_PROFILE_RING; r++)
+                for (int e = 0; e < 2; e++)
+                    if (ctx->ev[k][r][e]) (void)hipEventDestroy(ctx->ev[k][r][e]);
+        delete[] ctx->ev;
+    }
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     for (int i = 0; i < 2; i++) if (ctx->d_frames[i]) (void)hipFree(ctx->d_frames[i]);
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
@@ -179,18 +184,45 @@ int aof_set_force_generic(aof_ctx *ctx, int on)
 int aof_set_profiling(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
+    if (on && !ctx->ev) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        ctx->ev = new (std::nothrow) hipEvent_t[AOF_K_COUNT][AOF_PROFILE_RING][2]();
+        if (!ctx->ev) return fail(ctx, -ENOMEM, "event ring");
+        for (int k = 0; k < AOF_K_COUNT; k++)
+            for (int r = 0; r < AOF_PROFILE_RING; r++)
+                for (int e = 0; e < 2; e++) HIP_TRY(ctx, hipEventCreate(&ctx->ev[k][r][e]));
+    }
     ctx->profiling = on != 0;
-    for (int k = 0; k < AOF_K_COUNT; k++) ctx->ev_valid[k] = false;
+    if (on) for (int k = 0; k < AOF_K_COUNT; k++) ctx->ev_count[k] = 0;
+    return 0;
+}
+
+int aof_profile_count(const aof_ctx *ctx, int kernel_id)
+{
+    if (!ctx || kernel_id < 0 || kernel_id >= AOF_K_COUNT) return -EINVAL;
+    const int64_t n = ctx->ev_count[kernel_id];
+    return (int)(n < AOF_PROFILE_RING ? n : AOF_PROFILE_RING);
+}
+
+int aof_profile_ms(aof_ctx *ctx, int kernel_id, int index, float *ms)
+{
+    if (!ctx || !ms) return -EINVAL;
+    const int kept = aof_profile_count(ctx, kernel_id);
+    if (kept < 0 || index < 0 || index >= kept)
+        return fail(ctx, -EINVAL, "kernel %d has no timed launch %d", kernel_id, index);
+    const int64_t n = ctx->ev_count[kernel_id];
+    const int slot = (int)((n - kept + index) % AOF_PROFILE_RING);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[kernel_id][slot][1]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev[kernel_id][slot][0], ctx->ev[kernel_id][slot][1]));
     return 0;
 }
 
 int aof_kernel_ms(aof_ctx *ctx, int kernel_id, float *ms)
 {
-    if (!ctx || !ms || kernel_id < 0 || kernel_id >= AOF_K_COUNT) return -EINVAL;
-    if (!ctx->ev_valid[kernel_id]) return fail(ctx, -EINVAL, "kernel %d was not timed", kernel_id);
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[kernel_id][1]));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev[kernel_id][0], ctx->ev[kernel_id][1]));
-    return 0;
+    const int kept = ctx ? aof_profile_count(ctx, kernel_id) : -EINVAL;
+    if (kept < 0) return -EINVAL;
+    if (kept == 0) return fail(ctx, -EINVAL, "kernel %d was not timed", kernel_id);
+    return aof_profile_ms(ctx, kernel_id, kept - 1, ms);
 }
 
 int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_cur,

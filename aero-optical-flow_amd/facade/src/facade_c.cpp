@@ -1,0 +1,34 @@
+// Plain-C handles on the facade classes, so that non-C++ harnesses (the Python
+// tests via ctypes) drive the real C++ classes rather than a re-implementation.
+#include "flow_opencv.hpp"
+#include "flow_px4.hpp"
+
+extern "C" {
+
+void *aof_facade_px4_create(float fx, float fy, int output_rate, int w, int h, int search,
+			    int feature_threshold, int value_threshold)
+{
+	return new OpticalFlowPX4(fx, fy, output_rate, w, h, search, feature_threshold,
+				  value_threshold);
+}
+
+void *aof_facade_opencv_create(float fx, float fy, int output_rate, int w, int h)
+{
+	// exactly the five arguments /root/reference/src/mainloop.cpp:423-424 passes
+	return new OpticalFlowOpenCV(fx, fy, output_rate, w, h);
+}
+
+void aof_facade_destroy(void *flow) { delete static_cast<OpticalFlow *>(flow); }
+
+int aof_facade_calc_flow(void *flow, uint8_t *img, uint32_t t_us, int *dt_us, float *flow_x,
+			 float *flow_y)
+{
+	return static_cast<OpticalFlow *>(flow)->calcFlow(img, t_us, *dt_us, *flow_x, *flow_y);
+}
+
+int aof_facade_image_width(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageWidth(); }
+int aof_facade_image_height(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageHeight(); }
+const char *aof_facade_last_error(void *flow) { return static_cast<OpticalFlow *>(flow)->lastError(); }
+int aof_facade_default_output_rate(void) { return DEFAULT_OUTPUT_RATE; }
+
+}  // extern "C"

@@ -23,11 +23,14 @@ def canvas(width, height, reach, seed):
     return ((acc + 4) // 9).astype(np.uint8)
 
 
-def make_pair(width, height, reach=4, pair_index=0, shift=None, noise=0, brightness=0, contrast=1.0):
+def make_pair(width, height, reach=4, pair_index=0, shift=None, noise=0, brightness=0, contrast=1.0,
+              half=(0, 0)):
     """Returns (prev, cur, (dx, dy)).  ``shift=None`` draws (dx, dy) uniformly from
     [-reach, reach]^2 with the pair's RNG.  ``noise``: +-noise LSB added to cur;
     ``brightness``: constant added to cur (saturating) -- the exposure step the
-    reference's auto-exposure loop produces (/root/reference/src/mainloop.cpp:197-275)."""
+    reference's auto-exposure loop produces (/root/reference/src/mainloop.cpp:197-275);
+    ``half``: (hx, hy) in {-1,0,1}: an extra half-pixel displacement, made by averaging
+    the crop with its one-pixel neighbour (needs |shift| < reach on that axis)."""
     seed = SEED_BASE + int(pair_index)
     c = canvas(width, height, reach, seed)
     rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
@@ -38,6 +41,11 @@ def make_pair(width, height, reach=4, pair_index=0, shift=None, noise=0, brightn
     assert abs(dx) <= reach and abs(dy) <= reach
     prev = c[reach:reach + height, reach:reach + width].copy()
     cur = c[reach - dy:reach - dy + height, reach - dx:reach - dx + width].astype(np.int32)
+    if half != (0, 0):
+        hx, hy = half
+        assert abs(dx + hx) <= reach and abs(dy + hy) <= reach
+        nb = c[reach - dy - hy:reach - dy - hy + height, reach - dx - hx:reach - dx - hx + width]
+        cur = (cur + nb.astype(np.int32)) >> 1
     if contrast != 1.0:
         cur = np.rint((cur - 128) * contrast + 128).astype(np.int32)
     if noise:

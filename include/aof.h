@@ -146,10 +146,17 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow);
 int aof_stream_reset(aof_ctx *ctx);
 
 /* ---- measurement ----
- * With profiling on, every launch is bracketed by HIP events on its stream;
- * aof_kernel_ms() synchronises on them and returns the last launch's duration. */
+ * With profiling on, every launch is bracketed by HIP events on the stream it
+ * is launched on; the last AOF_PROFILE_RING launches of each kernel are kept.
+ * aof_kernel_ms() synchronises on the newest pair and returns its duration;
+ * aof_profile_count()/aof_profile_ms() walk the ring (index 0 = oldest kept)
+ * so a benchmark can average a kernel over its whole timed region.
+ * Turning profiling on resets the ring. */
+#define AOF_PROFILE_RING 256
 int aof_set_profiling(aof_ctx *ctx, int on);
 int aof_kernel_ms(aof_ctx *ctx, int kernel_id, float *ms);
+int aof_profile_count(const aof_ctx *ctx, int kernel_id);
+int aof_profile_ms(aof_ctx *ctx, int kernel_id, int index, float *ms);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,388 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Integer/byte work: the bar is bit-exact
+(block records compared as raw u32, flow records as raw 16 bytes).
+
+"Oracle" = this repo's restatement of the published PX4Flow algorithm + the
+build-defined extensions (parity unpinned: upstream PX4 source unavailable)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(aof, p, prevs, curs, device, force_generic=False, want_ws=False):
+    import torch
+    eng = aof.FlowEngine(p, 0)
+    if force_generic:
+        eng.force_generic(True)
+    tp = torch.from_numpy(np.ascontiguousarray(prevs)).to(device)
+    tc = torch.from_numpy(np.ascontiguousarray(curs)).to(device)
+    blocks, flows, ws = eng.flow_batch(tp, tc)
+    torch.cuda.synchronize()
+    out = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows), variant=eng.variant, eng=eng)
+    if want_ws:
+        out["ws"] = ws.cpu().numpy()
+    return out
+
+
+def check_against_oracle(aof, orc, p, prevs, curs, got, subdirs=None):
+    po = orc.params_from(p)
+    for i in range(prevs.shape[0]):
+        ref = orc.flow_pair(po, prevs[i], curs[i])
+        gb, rb = got["blocks"][i], ref["blocks"]
+        if gb.tobytes() != rb.tobytes():
+            bad = np.nonzero(gb.view(np.uint32) != rb.view(np.uint32))[0]
+            raise AssertionError(f"pair {i}: {bad.size} block records differ, first {bad[:5]}: "
+                                 f"gpu {gb[bad[:5]]} oracle {rb[bad[:5]]}")
+        assert got["flows"][i].tobytes() == ref["flow"].tobytes(), (i, got["flows"][i], ref["flow"])
+        if subdirs is not None:
+            assert np.array_equal(subdirs[i], ref["subdirs"]), i
+
+
+# ---- BASELINE configs ---------------------------------------------------------
+
+def test_c1_64x64_px4flow_grid(aof, orc, synth, gpu_device):
+    """configs[0]: 64x64, 8x8 SAD +-4, the published sparse grid with half-pixel refinement."""
+    import torch
+    p = aof.px4flow_params(64, 64)
+    prevs, curs, shifts = synth.make_batch(64, 64, 12, 4, 0, noise=2)
+    for i, half in enumerate([(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1), (1, -1), (-1, 1)]):
+        prevs[i], curs[i], _ = synth.make_pair(64, 64, 4, i, shift=(1 - i % 3, i % 2), half=half)
+    eng = aof.FlowEngine(p, 0)
+    assert eng.variant == "generic"
+    tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
+    sub = torch.empty((12, 25), dtype=torch.uint8, device=gpu_device)
+    blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+    torch.cuda.synchronize()
+    got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
+    check_against_oracle(aof, orc, p, prevs, curs, got, subdirs=sub.cpu().numpy())
+    seen = set(np.unique(sub.cpu().numpy()[:8]))
+    assert seen >= {0, 1, 2, 3, 4, 5, 6, 7}, f"half-pixel shifted pairs must exercise every direction: {seen}"
+
+
+def test_c1_64x64_dense(aof, orc, synth, gpu_device):
+    p = aof.default_params(64, 64)
+    prevs, curs, shifts = synth.make_batch(64, 64, 16, 4, 100)
+    got = run_gpu(aof, p, prevs, curs, gpu_device)
+    assert got["variant"] == "tile8_lds"
+    check_against_oracle(aof, orc, p, prevs, curs, got)
+    # analytic known answer, independent of any implementation
+    for i in range(16):
+        assert (got["blocks"][i]["dx"] == shifts[i, 0]).all() and (got["blocks"][i]["dy"] == shifts[i, 1]).all()
+        assert (got["blocks"][i]["sad"] == 0).all()
+        assert got["flows"][i]["flow_x"] == shifts[i, 0] and got["flows"][i]["quality"] == 255
+
+
+@pytest.mark.parametrize("noise,brightness", [(0, 0), (4, 0), (12, -20)])
+def test_c2_vga_8x8_bit_exact(aof, orc, synth, gpu_device, noise, brightness):
+    """configs[1]: 640x480, 8x8 SAD +-4, 1 GPU, bit-exact vs CPU."""
+    p = aof.default_params(640, 480)
+    prevs, curs, shifts = synth.make_batch(640, 480, 5, 4, 200 + noise, noise=noise, brightness=brightness)
+    got = run_gpu(aof, p, prevs, curs, gpu_device)
+    assert got["variant"] == "tile8_lds"
+    assert got["blocks"].shape == (5, 4661)
+    check_against_oracle(aof, orc, p, prevs, curs, got)
+
+
+def test_c2_generic_kernel_agrees(aof, orc, synth, gpu_device):
+    p = aof.default_params(640, 480)
+    prevs, curs, _ = synth.make_batch(640, 480, 2, 4, 300, noise=6)
+    a = run_gpu(aof, p, prevs, curs, gpu_device)
+    b = run_gpu(aof, p, prevs, curs, gpu_device, force_generic=True)
+    assert b["variant"] == "generic"
+    assert a["blocks"].tobytes() == b["blocks"].tobytes() and a["flows"].tobytes() == b["flows"].tobytes()
+    check_against_oracle(aof, orc, p, prevs, curs, b)
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_c3_vga_two_level_mean_subtracted(aof, orc, synth, gpu_device, force_generic):
+    """configs[2]: 640x480, 2-level mean-subtracted pyramid + 4x4 gate / histogram filter."""
+    p = aof.default_params(640, 480, pyramid_levels=2, mean_subtract=1)
+    # two levels reach 2S at level 1 (+ the level-0 refinement): keep |shift| <= 2S+1 = 9
+    prevs, curs, shifts = synth.make_batch(640, 480, 4, 9, 401, noise=3, brightness=13)
+    got = run_gpu(aof, p, prevs, curs, gpu_device, force_generic=force_generic, want_ws=True)
+    check_against_oracle(aof, orc, p, prevs, curs, got)
+    f = got["flows"]
+    assert (f["flags"] == 3).all()
+    big = np.abs(shifts).max(axis=1) > 4
+    assert big.any(), "the batch must contain shifts only the pyramid can reach"
+    assert np.array_equal(f["flow_x"], shifts[:, 0].astype(np.float32))
+    assert np.array_equal(f["flow_y"], shifts[:, 1].astype(np.float32))
+    # K1 intermediates against the oracle's building blocks
+    L = aof.workspace_layout(p, 4)
+    ws = got["ws"]
+    sums = ws[L.sums:L.sums + 4 * 16].view(np.uint32).reshape(4, 2, 2)
+    l1p = ws[L.l1_prev:L.l1_prev + 4 * 320 * 240].reshape(4, 240, 320)
+    l1c = ws[L.l1_cur:L.l1_cur + 4 * 320 * 240].reshape(4, 240, 320)
+    for i in range(4):
+        assert np.array_equal(l1p[i], orc.pyramid_down(prevs[i]))
+        assert np.array_equal(l1c[i], orc.pyramid_down(curs[i]))
+        assert sums[i, 0, 0] == prevs[i].sum(dtype=np.uint64) and sums[i, 1, 0] == curs[i].sum(dtype=np.uint64)
+        assert sums[i, 0, 1] == l1p[i].sum(dtype=np.uint64) and sums[i, 1, 1] == l1c[i].sum(dtype=np.uint64)
+    # level-1 records against the oracle
+    po = orc.params_from(p)
+    nb1 = 39 * 29
+    b1 = ws[L.l1_blocks:L.l1_blocks + 4 * nb1 * 4].view(aof.BLOCK_DTYPE).reshape(4, nb1)
+    for i in range(4):
+        ref = orc.flow_pair(po, prevs[i], curs[i], want_l1=True)
+        assert b1[i].tobytes() == ref["blocks_l1"].tobytes()
+
+
+def test_c5_1280x960_16x16_search8(aof, orc, synth, gpu_device):
+    """configs[4]: 1280x960, 16x16 SAD +-8 (LDS-tile stress)."""
+    p = aof.default_params(1280, 960, tile=16, search=8, value_threshold=12000)
+    prevs, curs, shifts = synth.make_batch(1280, 960, 2, 8, 500, noise=3)
+    got = run_gpu(aof, p, prevs, curs, gpu_device)
+    assert got["blocks"].shape == (2, 4661)
+    check_against_oracle(aof, orc, p, prevs, curs, got)
+    assert np.array_equal(got["flows"]["flow_x"], shifts[:, 0].astype(np.float32))
+
+
+def test_c4_batch_properties_at_full_size(aof, orc, synth, gpu_device):
+    """configs[3] per-GPU share: 128 independent VGA pairs in one launch.  The
+    oracle checks a sample; every pair is checked through the analytic property
+    (pure translation -> exact shift, SAD 0, quality 255)."""
+    import torch
+    p = aof.default_params(640, 480)
+    n = 128
+    prevs, curs, shifts = synth.make_batch(640, 480, n, 4, 1000)
+    got = run_gpu(aof, p, prevs, curs, gpu_device)
+    b, f = got["blocks"], got["flows"]
+    assert (b["sad"] == 0).all()
+    assert (b["dx"] == shifts[:, 0:1]).all() and (b["dy"] == shifts[:, 1:2]).all()
+    assert np.array_equal(f["flow_x"], shifts[:, 0].astype(np.float32))
+    assert np.array_equal(f["flow_y"], shifts[:, 1].astype(np.float32))
+    assert (f["quality"] == 255).all() and (f["count"] == 4661).all()
+    sample = [0, 1, 63, 127]
+    check_against_oracle(aof, orc, p, prevs[sample], curs[sample],
+                         dict(blocks=b[sample], flows=f[sample]))
+    # idempotence: a second run over the same resident batch gives the same bytes
+    again = run_gpu(aof, p, prevs, curs, gpu_device)
+    assert again["blocks"].tobytes() == b.tobytes() and again["flows"].tobytes() == f.tobytes()
+
+
+# ---- shapes, options and edge cases ---------------------------------------------
+
+SHAPES = [
+    dict(width=128, height=96),                                   # tile8 fast path, several strips
+    dict(width=136, height=72),                                   # width % 16 != 0 -> generic
+    dict(width=96, height=81),                                    # odd height, 1 level
+    dict(width=160, height=128, pyramid_levels=2),                # shifted tile8 path
+    dict(width=160, height=128, pyramid_levels=2, mean_subtract=1, hist_filter=0),
+    dict(width=100, height=90, mean_subtract=1),                  # sums via the scalar K1 path
+    dict(width=128, height=96, subpixel=1),                       # dense + half-pixel -> generic
+    dict(width=128, height=128, grid_mode=1, subpixel=1, num_blocks=7),
+    dict(width=128, height=96, grid_mode=1, subpixel=1, pyramid_levels=2, mean_subtract=1),
+    dict(width=96, height=96, tile=16, search=8, value_threshold=12000),
+    dict(width=96, height=96, tile=16, search=5, value_threshold=12000, subpixel=1),
+    dict(width=80, height=64, search=2),
+    dict(width=80, height=64, search=7, min_valid=0),
+    dict(width=1280, height=64),                                  # wide rows: strip planning
+]
+
+
+@pytest.mark.parametrize("case", range(len(SHAPES)))
+def test_shapes_and_options(aof, orc, synth, gpu_device, case):
+    import torch
+    kw = SHAPES[case]
+    p = aof.default_params(**kw)
+    reach = 2 * p.search + 1 if p.pyramid_levels == 2 else p.search
+    n = 6
+    prevs, curs, _ = synth.make_batch(p.width, p.height, n, reach, 2000 + 10 * case, noise=5,
+                                      brightness=7 if p.mean_subtract else 0)
+    rng = np.random.default_rng(case)
+    curs[n - 1] = rng.integers(0, 256, curs[n - 1].shape, dtype=np.uint8)  # unrelated frame
+    prevs[n - 2][: p.height // 2] = 90                                       # half the frame flat
+    eng = aof.FlowEngine(p, 0)
+    tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
+    nb = eng.nblocks(0)
+    sub = torch.full((n, nb), 99, dtype=torch.uint8, device=gpu_device) if p.subpixel else None
+    blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+    torch.cuda.synchronize()
+    got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
+    check_against_oracle(aof, orc, p, prevs, curs, got,
+                         subdirs=sub.cpu().numpy() if sub is not None else None)
+
+
+def test_flat_and_saturated_frames(aof, orc, gpu_device):
+    p = aof.default_params(128, 96)
+    prevs = np.stack([np.full((96, 128), v, np.uint8) for v in (0, 77, 255)])
+    got = run_gpu(aof, p, prevs, prevs.copy(), gpu_device)
+    assert (got["blocks"]["sad"] == 0xFFFF).all()
+    assert (got["flows"]["count"] == 0).all() and (got["flows"]["flags"] == 0).all()
+    check_against_oracle(aof, orc, p, prevs, prevs, got)
+
+
+def test_first_minimum_wins_on_periodic_texture(aof, orc, gpu_device):
+    p = aof.default_params(128, 96)
+    img = np.zeros((96, 128), np.uint8)
+    img[:, 0::2] = 200            # period 2 in x: five zero-SAD candidates per row of the scan
+    img2 = np.zeros((96, 128), np.uint8)
+    img2[0::4, :] = 150           # period 4 in y
+    prevs = np.stack([img, img2])
+    for force in (False, True):
+        got = run_gpu(aof, p, prevs, prevs.copy(), gpu_device, force_generic=force)
+        assert (got["blocks"][0]["dx"] == -4).all() and (got["blocks"][0]["dy"] == -4).all()
+        assert (got["blocks"][1]["dy"] == -4).all() and (got["blocks"][1]["dx"] == -4).all()
+        check_against_oracle(aof, orc, p, prevs, prevs, got)
+
+
+def test_extreme_sads_and_thresholds(aof, orc, gpu_device):
+    """Max-contrast checkerboards drive the packed u16 accumulators to 64*255."""
+    yy, xx = np.mgrid[0:96, 0:128]
+    a = (((xx // 8 + yy // 8) % 2) * 255).astype(np.uint8)
+    b = 255 - a
+    for kw in (dict(), dict(value_threshold=70000), dict(feature_threshold=0), dict(value_threshold=0)):
+        p = aof.default_params(128, 96, **kw)
+        prevs, curs = np.stack([a, b, a]), np.stack([b, a, a])
+        for force in (False, True):
+            got = run_gpu(aof, p, prevs, curs, gpu_device, force_generic=force)
+            check_against_oracle(aof, orc, p, prevs, curs, got)
+    p = aof.default_params(128, 96, tile=16, search=8, value_threshold=70000, feature_threshold=0)
+    got = run_gpu(aof, p, np.stack([a]), np.stack([b]), gpu_device)
+    check_against_oracle(aof, orc, p, np.stack([a]), np.stack([b]), got)
+
+
+def test_mean_equalisation_saturates_like_the_oracle(aof, orc, synth, gpu_device):
+    p = aof.default_params(128, 96, mean_subtract=1)
+    prev, cur, _ = synth.make_pair(128, 96, 4, 77, contrast=2.5)
+    dark = np.clip(cur.astype(np.int32) - 90, 0, 255).astype(np.uint8)   # delta > 0, clips at 255
+    bright = np.clip(cur.astype(np.int32) + 90, 0, 255).astype(np.uint8)  # delta < 0, clips at 0
+    prevs, curs = np.stack([prev, prev, prev]), np.stack([dark, bright, cur])
+    for force in (False, True):
+        got = run_gpu(aof, p, prevs, curs, gpu_device, force_generic=force)
+        check_against_oracle(aof, orc, p, prevs, curs, got)
+
+
+def test_predictor_pushes_windows_out_of_frame(aof, orc, synth, gpu_device):
+    """2 levels, large shift: edge blocks' displaced windows leave the frame and are skipped."""
+    p = aof.default_params(192, 160, pyramid_levels=2)
+    for shift in ((9, 8), (-9, -8), (8, -9), (-7, 9), (6, 0)):
+        prev, cur, _ = synth.make_pair(192, 160, 12, 5, shift=shift)
+        for force in (False, True):
+            got = run_gpu(aof, p, prev[None], cur[None], gpu_device, force_generic=force)
+            check_against_oracle(aof, orc, p, prev[None], cur[None], got)
+            sk = got["blocks"][0]["sad"] == 0xFFFF
+            assert sk.any() and not sk.all()
+
+
+def test_frame_sequence_via_pair_stride(aof, orc, synth, gpu_device):
+    """A resident frame SEQUENCE: pair k = (frame k, frame k+1), no copies."""
+    import torch
+    p = aof.default_params(128, 96)
+    frames, steps = synth.make_sequence(128, 96, 9, 4, seed=4)
+    t = torch.from_numpy(frames).to(gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    blocks, flows, _ = eng.flow_batch(t[:-1], t[1:], n_pairs=8, pair_stride=128 * 96)
+    torch.cuda.synchronize()
+    got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
+    check_against_oracle(aof, orc, p, frames[:-1], frames[1:], got)
+    assert np.array_equal(got["flows"]["flow_x"], steps[:, 0].astype(np.float32))
+
+
+def test_padded_pair_stride_and_caller_buffers(aof, orc, synth, gpu_device):
+    import torch
+    p = aof.default_params(128, 96)
+    prevs, curs, _ = synth.make_batch(128, 96, 3, 4, 900, noise=2)
+    stride = 128 * 96 + 256
+    bp = torch.zeros(3 * stride, dtype=torch.uint8, device=gpu_device)
+    bc = torch.zeros(3 * stride, dtype=torch.uint8, device=gpu_device)
+    for i in range(3):
+        bp[i * stride:i * stride + 128 * 96] = torch.from_numpy(prevs[i].ravel()).to(gpu_device)
+        bc[i * stride:i * stride + 128 * 96] = torch.from_numpy(curs[i].ravel()).to(gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    blocks, flows, _ = eng.flow_batch(bp, bc, n_pairs=3, pair_stride=stride)
+    torch.cuda.synchronize()
+    check_against_oracle(aof, orc, p, prevs, curs,
+                         dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows)))
+
+
+def test_empty_batch_and_errors(aof, gpu_device):
+    import torch
+    p = aof.default_params(128, 96)
+    eng = aof.FlowEngine(p, 0)
+    z = torch.empty((0, 96, 128), dtype=torch.uint8, device=gpu_device)
+    blocks, flows, _ = eng.flow_batch(z, z, n_pairs=0, pair_stride=128 * 96)
+    assert blocks.shape[0] == 0
+    t = torch.zeros((2, 96, 128), dtype=torch.uint8, device=gpu_device)
+    small = torch.zeros(256, dtype=torch.uint8, device=gpu_device)
+    with pytest.raises(aof.AofError) as e:
+        eng.flow_batch(t, t, workspace=small)
+    assert e.value.code == -28  # -ENOSPC
+    with pytest.raises(aof.AofError):
+        aof.FlowEngine(p, 99)  # no such device
+
+
+def test_host_pair_and_streaming_entry_points(aof, orc, synth, gpu_device):
+    p = aof.px4flow_params(64, 64)
+    eng = aof.FlowEngine(p, 0)
+    po = orc.params_from(p)
+    prev, cur, _ = synth.make_pair(64, 64, 4, 31, noise=3)
+    blocks, subdirs, flow = eng.flow_pair_host(prev, cur)
+    ref = orc.flow_pair(po, prev, cur)
+    assert blocks.tobytes() == ref["blocks"].tobytes() and np.array_equal(subdirs, ref["subdirs"])
+    assert flow.tobytes() == ref["flow"].tobytes()
+    frames, _ = synth.make_sequence(64, 64, 6, 4, seed=9, max_step=3)
+    assert eng.stream_push(frames[0]) is None
+    for k in range(1, 6):
+        f = eng.stream_push(frames[k])
+        assert f.tobytes() == orc.flow_pair(po, frames[k - 1], frames[k])["flow"].tobytes()
+    eng.stream_reset()
+    assert eng.stream_push(frames[3]) is None
+
+
+@pytest.mark.parametrize("cls", ["OpticalFlowPX4", "OpticalFlowOpenCV"])
+def test_facade_calcflow_matches_oracle(aof, orc, synth, gpu_device, cls):
+    """The C++ facade classes (calcFlow contract of mainloop.cpp:322-331) through
+    the HIP engine, against the oracle of the same semantics -- bit-exact floats."""
+    fx, fy = 216.6677, 216.2457  # /root/reference/src/main.cpp:60-61
+    for rate, size in ((15, (64, 64)), (0, (64, 64)), (40, (128, 128)), (15, (128, 96))):
+        flow = getattr(aof, cls)(fx, fy, rate, size[0], size[1])
+        assert flow.lastError() == "ok"
+        assert (flow.getImageWidth(), flow.getImageHeight()) == size
+        o = orc.Px4(orc.px4flow_params(*size), fx, fy, rate)
+        frames, _ = synth.make_sequence(size[0], size[1], 30, 4, seed=rate, max_step=2)
+        t, published = 0, 0
+        for k in range(30):
+            got = flow.calcFlow(frames[k], t)
+            exp = o.calc_flow(frames[k], t)
+            assert got[0] == exp[0], (rate, k, got, exp)
+            if exp[0] >= 0 and k > 0:
+                published += 1
+                assert got[1] == exp[1]
+                assert np.float32(got[2]).tobytes() == np.float32(exp[2]).tobytes()
+                assert np.float32(got[3]).tobytes() == np.float32(exp[3]).tobytes()
+            t += 13333
+        assert published >= (4 if rate == 15 else 20)
+        flow.close()
+
+
+def test_replay_harness_links_and_matches_oracle(aof, orc, synth, gpu_device, tmp_path):
+    """replay_mainloop.cpp replays mainloop.cpp:295-331 (crop, contiguous copy, calcFlow,
+    negative gate) against <flow_opencv.hpp> with the reference's argument types."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(aof.FACADE_PATH), "replay", "replay_mainloop")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    cam_w, cam_h, crop = 320, 240, 128  # the reference's defaults, main.cpp:54-58
+    frames, _ = synth.make_sequence(cam_w, cam_h, 24, 4, seed=5, max_step=3)
+    raw = tmp_path / "frames.raw"
+    raw.write_bytes(frames.tobytes())
+    out = subprocess.run([exe, str(raw), str(cam_w), str(cam_h), str(crop), str(crop), "75"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if not l.startswith("#")]
+    assert "engine: ok" in out.stdout and "DEFAULT_OUTPUT_RATE=15" in out.stdout
+    o = orc.Px4(orc.px4flow_params(crop, crop), 216.6677, 216.2457, 15)
+    x0, y0 = cam_w // 2 - crop // 2, cam_h // 2 - crop // 2
+    n_pub = 0
+    for k in range(24):
+        t = int(1000000 + int(k * 1.0e6 / 75)) - 1000000 if k else 0
+        q, dt, ax, ay = o.calc_flow(frames[k, y0:y0 + crop, x0:x0 + crop], t)
+        if q < 0:
+            assert lines[k] == f"{k} skip"
+        else:
+            n_pub += 1
+            assert lines[k] == (f"{k} quality={q} integration_time_us={dt} "
+                                f"integrated_x={ax:.9g} integrated_y={ay:.9g}"), (lines[k], q, dt, ax, ay)
+    assert n_pub >= 4
