@@ -3,7 +3,10 @@
 // One workgroup per frame pair.  The block records (4 B each, just written by
 // K2 and still in L2) are read coalesced; accepted blocks vote into two
 // half-pixel shift histograms held in LDS (integer LDS atomics, so the result
-// does not depend on arrival order).  Lane 0 then applies the published
+// does not depend on arrival order).  Neighbouring blocks mostly vote for the
+// SAME bin, which would serialise a plain per-lane LDS atomic 64 ways, so votes
+// are first aggregated across the wave (ballot of equal bins, one atomic per
+// distinct bin).  Lane 0 then applies the published
 // first-maximum peak search and the +-2-bin weighted mean, or the plain
 // average, and writes the 16-byte aof_flow.  The float arithmetic is a handful
 // of exactly-representable integers and two correctly-rounded divisions
@@ -35,6 +38,19 @@ __device__ __forceinline__ long long floor_div(long long a, long long b)
     return q;
 }
 
+// Adds one vote per active lane to hist[bin]: one LDS atomic per distinct bin in the wave.
+__device__ __forceinline__ void wave_vote(uint32_t *hist, int bin, bool active)
+{
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bin, leader, 64);
+        const unsigned long long same = __ballot(active && bin == b) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
 {
     __shared__ uint32_t hist[2][kMaxHist];
@@ -48,23 +64,34 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
     const aof_block *blocks = a.blocks + pair * a.nblocks;
     const uint8_t *subdirs = a.subdirs ? a.subdirs + pair * a.nblocks : nullptr;
     int s2x = 0, s2y = 0, cnt = 0;
-    for (int b = threadIdx.x; b < a.nblocks; b += kThreads) {
-        const aof_block r = blocks[b];
-        if (r.sad == AOF_SAD_SKIPPED || (int)r.sad >= a.value_threshold) continue;
-        int hx = 0, hy = 0;
-        if (subdirs) {
-            const int sd = subdirs[b];
-            hx = (sd == 0 || sd == 1 || sd == 7) ? 1 : ((sd == 3 || sd == 4 || sd == 5) ? -1 : 0);
-            hy = (sd == 1 || sd == 2 || sd == 3) ? 1 : ((sd == 5 || sd == 6 || sd == 7) ? -1 : 0);
+    const int rounds = (a.nblocks + kThreads - 1) / kThreads;  // uniform trip count: ballots need every lane
+    for (int it = 0; it < rounds; it++) {
+        const int b = it * kThreads + (int)threadIdx.x;
+        bool ok = b < a.nblocks;
+        int vx = 0, vy = 0;
+        if (ok) {
+            const aof_block r = blocks[b];
+            ok = !(r.sad == AOF_SAD_SKIPPED || (int)r.sad >= a.value_threshold);
+            int hx = 0, hy = 0;
+            if (ok && subdirs) {
+                const int sd = subdirs[b];
+                hx = (sd == 0 || sd == 1 || sd == 7) ? 1 : ((sd == 3 || sd == 4 || sd == 5) ? -1 : 0);
+                hy = (sd == 1 || sd == 2 || sd == 3) ? 1 : ((sd == 5 || sd == 6 || sd == 7) ? -1 : 0);
+            }
+            vx = 2 * r.dx + hx; vy = 2 * r.dy + hy;
         }
-        const int vx = 2 * r.dx + hx, vy = 2 * r.dy + hy;
-        atomicAdd(&hist[0][vx + centre], 1u);
-        atomicAdd(&hist[1][vy + centre], 1u);
-        s2x += vx; s2y += vy; cnt++;
+        wave_vote(hist[0], vx + centre, ok);
+        wave_vote(hist[1], vy + centre, ok);
+        if (ok) { s2x += vx; s2y += vy; cnt++; }
     }
-    atomicAdd(&sums[0], s2x);
-    atomicAdd(&sums[1], s2y);
-    atomicAdd(&sums[2], cnt);
+    s2x = (int)wave_sum_u32((uint32_t)s2x);
+    s2y = (int)wave_sum_u32((uint32_t)s2y);
+    cnt = (int)wave_sum_u32((uint32_t)cnt);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[0], s2x);
+        atomicAdd(&sums[1], s2y);
+        atomicAdd(&sums[2], cnt);
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
     {

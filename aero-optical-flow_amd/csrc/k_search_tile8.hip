@@ -28,7 +28,15 @@ namespace aof {
 namespace {
 
 constexpr int kMaxThreads = 512;
-constexpr int kLdsBudget = 64 * 1024;
+constexpr int kLdsBudget = 80 * 1024;  // two workgroups per CU at the least
+
+#ifdef AOF_LAB  // experiment knobs of tools/k2_lab.hip; never defined in the product build
+int g_lab_rb = 0;           // force the strip height
+__constant__ int c_lab_mode;  // 1: skip staging loads, 2: skip the search
+#define LAB_MODE c_lab_mode
+#else
+#define LAB_MODE 0
+#endif
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 {
@@ -65,7 +73,9 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     const uint8_t *g_prev = a.prev + pair * a.pair_stride + (int64_t)(8 * by0 + 4) * W;
     const int cur_chunks = r_hi > r_lo ? (r_hi - r_lo) * (W / 16) : 0;
     const int prev_chunks = 8 * rows * (W / 16);
-    if (delta == 0) {
+    if (LAB_MODE == 1) {
+        // lab: no global traffic
+    } else if (delta == 0) {
         for (int c = tid; c < cur_chunks; c += nthreads)
             *reinterpret_cast<uint4 *>(s_cur + (size_t)r_lo * W + (size_t)c * 16) =
                 *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
@@ -77,10 +87,18 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
             *reinterpret_cast<uint4 *>(s_cur + (size_t)r_lo * W + (size_t)c * 16) = v;
         }
     }
+    if (LAB_MODE != 1)
     for (int c = tid; c < prev_chunks; c += nthreads)
         *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) =
             *reinterpret_cast<const uint4 *>(g_prev + (size_t)c * 16);
     __syncthreads();
+    if (LAB_MODE == 2) {
+        if (tid < rows * nx) {
+            aof_block z; z.dx = (int8_t)s_cur[tid]; z.dy = (int8_t)s_prev[tid]; z.sad = 0;
+            a.blocks[pair * (int64_t)(nx * ny) + (int64_t)by0 * nx + tid] = z;
+        }
+        return;
+    }
 
     // ---- one block per lane ----
     if (tid >= rows * nx) return;
@@ -188,12 +206,23 @@ struct Tile8Plan { int rb, threads, nstrips; size_t lds; };
 
 Tile8Plan plan_tile8(const SearchArgs &a)
 {
-    // Pick the strip height that keeps most lanes busy over the whole frame.
+    // Pick the strip height that keeps most lanes busy over the whole frame.  Workgroups
+    // are whole multiples of 256 threads (one wave per SIMD): measured on MI355X, a
+    // 5-wave workgroup with better lane use (rb=4 at VGA, 97 %) ran 33 % slower than the
+    // 4-wave one (rb=3, 91 %) because fewer workgroups fit a CU and staging stops
+    // overlapping with the search (profiles/r01_b_k2_lab.txt).
     Tile8Plan best = {0, 0, 0, 0};
     double best_eff = -1.0;
     for (int rb = 1; rb <= 16; rb++) {
+#ifdef AOF_LAB
+        if (g_lab_rb && rb != g_lab_rb) continue;
+#endif
         const int items = rb * a.grid.nx;
-        const int threads = (items + 63) / 64 * 64;
+#ifdef AOF_LAB
+        const int threads = g_lab_rb ? (items + 63) / 64 * 64 : (items + 255) / 256 * 256;
+#else
+        const int threads = (items + 255) / 256 * 256;
+#endif
         const size_t lds = (size_t)(16 * rb + 8) * a.w + 16;
         if (threads > kMaxThreads || lds > (size_t)kLdsBudget) break;
         const int nstrips = (a.grid.ny + rb - 1) / rb;

@@ -70,6 +70,19 @@ def make_batch_gpu(width, height, n, reach, seed, device, brightness=0):
     return prev, cur, hs
 
 
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota when there is one
+    (the GPU box gives each GPU a 16-core share of a 256-thread host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,7 +207,7 @@ def main():
                          "all_pairs_return_known_shift": known,
                          "note": "oracle = this repo's CPU restatement (upstream PX4 source unavailable)"}
         if world == 1 and args.cpu_seconds > 0:
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = host_cores()
             m = min(n, max(4 * cores, 16))
             hp, hc = prev[:m].cpu().numpy(), cur[:m].cpu().numpy()
             done, used, spent = 0, cores, 0.0

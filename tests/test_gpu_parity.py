@@ -353,7 +353,7 @@ def test_facade_calcflow_matches_oracle(aof, orc, synth, gpu_device, cls):
                 assert np.float32(got[2]).tobytes() == np.float32(exp[2]).tobytes()
                 assert np.float32(got[3]).tobytes() == np.float32(exp[3]).tobytes()
             t += 13333
-        assert published >= (4 if rate == 15 else 20)
+        assert published >= {15: 4, 0: 29, 40: 14}[rate]
         flow.close()
 
 
