@@ -109,6 +109,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     aof = ge.load_package()
+    import importlib
+    batch = importlib.import_module(ge.PKG_NAME + ".batch")
     desc, W, H, over, reach = WORKLOADS[args.workload]
     p = aof.default_params(W, H, **over)
     eng = aof.FlowEngine(p, local_rank)
@@ -120,12 +122,11 @@ def main():
     flows = torch.empty((n, 16), dtype=torch.uint8, device=device)
     L = aof.workspace_layout(p, n)
     ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=device)
-    gathered = torch.empty((world * n, 16), dtype=torch.uint8, device=device) if world > 1 else None
 
     def step():
         eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, flows)  # the only exchange: 16 B per pair
+        # the only exchange of the batched mode: 16 B per pair, every rank gets all flows
+        return batch.gather_flows(flows, world * n) if world > 1 else flows
 
     def fence():
         torch.cuda.synchronize(device)
