@@ -100,6 +100,7 @@ int run_search(aof_ctx *ctx, const SearchArgs &a, hipStream_t s)
 {
     int rc;
     if (!ctx->force_generic && tile8_supported(a)) rc = launch_search_tile8(a, s);
+    else if (!ctx->force_generic && tile16_supported(a)) rc = launch_search_tile16(a, s);
     else rc = launch_search_generic(a, s);
     if (rc) return fail(ctx, -EIO, "search launch: %s", hipGetErrorString((hipError_t)rc));
     return 0;
@@ -134,7 +135,7 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
     // which search kernel will level 0 use? (probe with aligned dummy pointers)
     SearchArgs probe = search_args(ctx, 0, nullptr, nullptr, (int64_t)p->width * p->height, nullptr,
                                    nullptr, nullptr, nullptr, 1);
-    ctx->variant = tile8_supported(probe) ? "tile8_lds" : "generic";
+    ctx->variant = tile8_supported(probe) ? "tile8_lds" : (tile16_supported(probe) ? "tile16_lds" : "generic");
     *out = ctx;
     return 0;
 }

@@ -75,6 +75,9 @@ int launch_search_generic(const SearchArgs &a, void *stream);
 // half-pixel refinement.  tile8_supported() says whether `a` qualifies.
 bool tile8_supported(const SearchArgs &a);
 int launch_search_tile8(const SearchArgs &a, void *stream);
+// LDS-tiled (block, dy)-per-lane kernel for B=16, S=8 on a dense grid, no predictor.
+bool tile16_supported(const SearchArgs &a);
+int launch_search_tile16(const SearchArgs &a, void *stream);
 int launch_reduce(const ReduceArgs &a, void *stream);
 
 }  // namespace aof

@@ -252,6 +252,12 @@ int launch_search_tile8(const SearchArgs &a, void *stream)
     const int64_t total = a.n_pairs * p.nstrips;
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p.lds > 64 * 1024) {  // beyond the default dynamic-LDS window
+        const void *fn = a.pred ? reinterpret_cast<const void *>(k_search_tile8<true>)
+                                : reinterpret_cast<const void *>(k_search_tile8<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        if (e != hipSuccess) return (int)e;
+    }
     if (a.pred)
         hipLaunchKernelGGL(k_search_tile8<true>, dim3((uint32_t)total), dim3(p.threads), p.lds, s, a,
                            p.rb, p.nstrips, (uint32_t)total);
