@@ -32,6 +32,7 @@ constexpr int kLdsBudget = 80 * 1024;  // two workgroups per CU at the least
 
 #ifdef AOF_LAB  // experiment knobs of tools/k2_lab.hip; never defined in the product build
 int g_lab_rb = 0;           // force the strip height
+int g_lab_dyg = 0;          // force the dy group size (9 or 3)
 __constant__ int c_lab_mode;  // 1: skip staging loads, 2: skip the search
 #define LAB_MODE c_lab_mode
 #else
@@ -44,10 +45,15 @@ __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 }
 __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | lo; }
 
-template <bool SHIFTED>
+// DYG = vertical candidate offsets (dy) evaluated per lane: 9 = the whole block in one
+// lane; 3 = three lanes per block, each doing three of the nine dy rows (less state per
+// lane, smaller strips, more resident waves); the partial minima of a block then meet in
+// an LDS atomicMin on the packed key -- integer min, so still exactly first-minimum-wins.
+template <int DYG, bool SHIFTED>
 __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int rb, int nstrips,
                                                               uint32_t total_wgs)
 {
+    constexpr int NG = 9 / DYG;  // lanes per block
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const uint32_t logical = xcd_remap(blockIdx.x, total_wgs);
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     const int r_hi = min(n_cur_rows, H - yc0);
     uint8_t *s_cur = smem;
     uint8_t *s_prev = smem + (size_t)(8 * rb + 8) * W;
+    uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + (size_t)(16 * rb + 8) * W + 16);
     const uint8_t *g_cur = a.cur + pair * a.pair_stride + (int64_t)(yc0 + r_lo) * W;
     const uint8_t *g_prev = a.prev + pair * a.pair_stride + (int64_t)(8 * by0 + 4) * W;
     const int cur_chunks = r_hi > r_lo ? (r_hi - r_lo) * (W / 16) : 0;
@@ -91,6 +98,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     for (int c = tid; c < prev_chunks; c += nthreads)
         *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) =
             *reinterpret_cast<const uint4 *>(g_prev + (size_t)c * 16);
+    if (NG > 1)
+        for (int b = tid; b < rows * nx; b += nthreads) s_best[b] = 0xFFFFFFFFu;
     __syncthreads();
     if (LAB_MODE == 2) {
         if (tid < rows * nx) {
@@ -100,9 +109,14 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         return;
     }
 
-    // ---- one block per lane ----
-    if (tid >= rows * nx) return;
-    const int brow = tid / nx, bx = tid % nx;
+    // ---- one (block, dy group) per lane; group-major so that group 0 = lanes [0, rows*nx) ----
+    const int nblk = rows * nx;
+    const bool live = tid < nblk * NG;
+    if (NG == 1 && !live) return;
+    const int grp = live ? tid / nblk : 0, blk = live ? tid - grp * nblk : 0;
+    const int brow = blk / nx, bx = blk % nx;
+    constexpr int kRows = DYG + 7;                // search rows this lane streams
+    const int s0 = grp * DYG;                     // first dy index of the group
     bool inside = true;
     int xs = 8 * bx;                              // LDS byte column of the window start
     if (SHIFTED) {
@@ -139,15 +153,15 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     }
 
     // accumulators: per dy, offsets 0..3 / 4..7 packed u16, offset 8 as (sad<<16 | idx)
-    u64 acc_lo[9], acc_hi[9];
-    uint32_t acc_8[9];
+    u64 acc_lo[DYG], acc_hi[DYG];
+    uint32_t acc_8[DYG];
 #pragma unroll
-    for (int d = 0; d < 9; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)(d * 9 + 8); }
+    for (int d = 0; d < DYG; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)((s0 + d) * 9 + 8); }
 
     const int sh = SHIFTED ? (px & 3) : 0;
-    const uint8_t *win = s_cur + (size_t)(8 * brow) * W + (SHIFTED ? (xs & ~3) : xs);
+    const uint8_t *win = s_cur + (size_t)(8 * brow + s0) * W + (SHIFTED ? (xs & ~3) : xs);
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
+    for (int s = 0; s < kRows; s++) {
         uint32_t w0, w1, w2, w3;
         if (SHIFTED) {
             const uint32_t *p = reinterpret_cast<const uint32_t *>(win + (size_t)s * W);
@@ -164,8 +178,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         const u64 p01 = pack64(w0, w1), p12 = pack64(w1, w2), p23 = pack64(w2, w3);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const int d = s - r;  // dy index 0..8 (dy = d - 4)
-            if (d < 0 || d > 8) continue;
+            const int d = s - r;  // dy index within the group (dy = s0 + d - 4)
+            if (d < 0 || d >= DYG) continue;
             acc_lo[d] = qsad(p01, ref[r][0], acc_lo[d]);
             acc_lo[d] = qsad(p12, ref[r][1], acc_lo[d]);
             acc_hi[d] = qsad(p12, ref[r][0], acc_hi[d]);
@@ -178,8 +192,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     // arg-min over the 81 packed keys, scan order = key order
     uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
-    for (int d = 0; d < 9; d++) {
-        const uint32_t base = (uint32_t)(d * 9);
+    for (int d = 0; d < DYG; d++) {
+        const uint32_t base = (uint32_t)((s0 + d) * 9);
         const uint32_t l0 = (uint32_t)acc_lo[d], l1 = (uint32_t)(acc_lo[d] >> 32);
         const uint32_t h0 = (uint32_t)acc_hi[d], h1 = (uint32_t)(acc_hi[d] >> 32);
         const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
@@ -191,6 +205,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         best = min(best, min(min(k6, k7), acc_8[d]));
     }
 
+    if (NG > 1) {
+        if (live) atomicMin(&s_best[blk], best);
+        __syncthreads();
+        if (!live || grp != 0) return;
+        best = s_best[blk];
+    }
     aof_block rec;
     rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
     if (inside && diff >= (uint32_t)a.feature_threshold) {
@@ -202,7 +222,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     a.blocks[pair * (int64_t)(nx * ny) + (int64_t)(by0 + brow) * nx + bx] = rec;
 }
 
-struct Tile8Plan { int rb, threads, nstrips; size_t lds; };
+struct Tile8Plan { int rb, threads, nstrips, dyg; size_t lds; };
 
 Tile8Plan plan_tile8(const SearchArgs &a)
 {
@@ -211,23 +231,27 @@ Tile8Plan plan_tile8(const SearchArgs &a)
     // 5-wave workgroup with better lane use (rb=4 at VGA, 97 %) ran 33 % slower than the
     // 4-wave one (rb=3, 91 %) because fewer workgroups fit a CU and staging stops
     // overlapping with the search (profiles/r01_b_k2_lab.txt).
-    Tile8Plan best = {0, 0, 0, 0};
+    Tile8Plan best = {0, 0, 0, 0, 0};
     double best_eff = -1.0;
+    int dyg = 9;  // measured: 3 lanes per block (dyg = 3) is 11 % slower at VGA (profiles/r01_c_k2_lab_dyg.txt)
+#ifdef AOF_LAB
+    if (g_lab_dyg) dyg = g_lab_dyg;
+#endif
     for (int rb = 1; rb <= 16; rb++) {
 #ifdef AOF_LAB
         if (g_lab_rb && rb != g_lab_rb) continue;
 #endif
-        const int items = rb * a.grid.nx;
+        const int items = rb * a.grid.nx * (9 / dyg);
 #ifdef AOF_LAB
         const int threads = g_lab_rb ? (items + 63) / 64 * 64 : (items + 255) / 256 * 256;
 #else
         const int threads = (items + 255) / 256 * 256;
 #endif
-        const size_t lds = (size_t)(16 * rb + 8) * a.w + 16;
+        const size_t lds = (size_t)(16 * rb + 8) * a.w + 16 + 4 * (size_t)(rb * a.grid.nx);
         if (threads > kMaxThreads || lds > (size_t)kLdsBudget) break;
         const int nstrips = (a.grid.ny + rb - 1) / rb;
-        const double eff = (double)a.grid.blocks() / ((double)nstrips * threads);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = {rb, threads, nstrips, lds}; }
+        const double eff = (double)a.grid.blocks() * (9 / dyg) / ((double)nstrips * threads);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = {rb, threads, nstrips, dyg, lds}; }
     }
     return best;
 }
@@ -252,18 +276,16 @@ int launch_search_tile8(const SearchArgs &a, void *stream)
     const int64_t total = a.n_pairs * p.nstrips;
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    void (*fn)(SearchArgs, int, int, uint32_t);
+    if (p.dyg == 9) fn = a.pred ? k_search_tile8<9, true> : k_search_tile8<9, false>;
+    else fn = a.pred ? k_search_tile8<3, true> : k_search_tile8<3, false>;
     if (p.lds > 64 * 1024) {  // beyond the default dynamic-LDS window
-        const void *fn = a.pred ? reinterpret_cast<const void *>(k_search_tile8<true>)
-                                : reinterpret_cast<const void *>(k_search_tile8<false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         if (e != hipSuccess) return (int)e;
     }
-    if (a.pred)
-        hipLaunchKernelGGL(k_search_tile8<true>, dim3((uint32_t)total), dim3(p.threads), p.lds, s, a,
-                           p.rb, p.nstrips, (uint32_t)total);
-    else
-        hipLaunchKernelGGL(k_search_tile8<false>, dim3((uint32_t)total), dim3(p.threads), p.lds, s,
-                           a, p.rb, p.nstrips, (uint32_t)total);
+    hipLaunchKernelGGL(fn, dim3((uint32_t)total), dim3(p.threads), p.lds, s, a, p.rb, p.nstrips,
+                       (uint32_t)total);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (gpurun_out/pmc/<PASS>/.../*_counter_collection.csv)
+for the aof kernels: per-kernel mean counter values, and the HBM traffic per launch
+corrected as /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes for gfx950:
+FETCH_SIZE (KB) reads exactly half of a wide coalesced 16-B/lane stream -> x2;
+WRITE_SIZE (KB) is exact for 16-B/lane stores.  Writes profiles/pmc_traffic.json
+entries keyed "<workload>:<pairs>" that bench.py reports as roofline.traffic."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    root, workload, pairs, out_txt = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "aof::" not in k:
+                continue
+            k = k.split("(anonymous namespace)::")[-1].split("(")[0]
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines = [f"# rocprofv3 --pmc summary, workload {workload}, {pairs} pairs per launch (means over launches)"]
+    traffic = {}
+    for k in sorted(acc):
+        lines.append(k)
+        for c in sorted(acc[k]):
+            v = acc[k][c]
+            lines.append(f"    {c:<24} n={len(v):<3} mean={sum(v)/len(v):.6g}")
+        if "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+            rd = 2.0 * 1024.0 * sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
+            wr = 1024.0 * sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
+            traffic[k] = (rd, wr)
+            lines.append(f"    => HBM read {rd/1e6:.1f} MB (FETCH_SIZE x2, gfx950 correction) + write {wr/1e6:.1f} MB per launch")
+    open(out_txt, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    search = [k for k in traffic if k.startswith("k_search")]
+    if search:
+        rd, wr = traffic[search[0]]
+        path = os.path.join(os.path.dirname(os.path.abspath(out_txt)), "pmc_traffic.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[f"{workload}:{pairs}"] = {"kernel": search[0], "hbm_bytes_per_launch": int(rd + wr),
+                                       "read_bytes": int(rd), "write_bytes": int(wr),
+                                       "source": os.path.basename(out_txt)}
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
