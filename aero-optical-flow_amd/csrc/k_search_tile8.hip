@@ -16,10 +16,12 @@
 // keys (sad << 16 | idx), i.e. "first minimum in scan order wins".
 //
 // With the dense grid origin at S = 4 and step 8 every search window starts on
-// an 8-byte boundary, so the unshifted variant reads LDS with ds_read_b64 and
-// needs no byte realignment.  The SHIFTED variant (level 0 of the 2-level
-// pyramid, window displaced by the per-pair predictor) reads five dwords per
-// row and realigns with v_alignbyte_b32 by the wave-uniform (px & 3).
+// an 8-byte boundary, so LDS is read with ds_read_b64 and needs no byte
+// realignment.  The SHIFTED variant (level 0 of the 2-level pyramid, window
+// displaced by the per-pair predictor (px, py)) keeps that property by staging
+// the cur rows PRE-SHIFTED: the flat copy simply starts (px & 7) bytes later in
+// HBM, so LDS column c holds frame column c + (px & 7) and a block's window sits
+// at the 8-aligned LDS column 8*(bx + (px >> 3)).  The search loop is identical.
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 
@@ -76,23 +78,34 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     uint8_t *s_cur = smem;
     uint8_t *s_prev = smem + (size_t)(8 * rb + 8) * W;
     uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + (size_t)(16 * rb + 8) * W + 16);
-    const uint8_t *g_cur = a.cur + pair * a.pair_stride + (int64_t)(yc0 + r_lo) * W;
+    const int sh7 = SHIFTED ? (px & 7) : 0;        // floor-mod: px = 8*(px >> 3) + sh7
+    const uint8_t *g_cur = a.cur + pair * a.pair_stride + (int64_t)(yc0 + r_lo) * W + sh7;
     const uint8_t *g_prev = a.prev + pair * a.pair_stride + (int64_t)(8 * by0 + 4) * W;
-    const int cur_chunks = r_hi > r_lo ? (r_hi - r_lo) * (W / 16) : 0;
+    int cur_chunks = r_hi > r_lo ? (r_hi - r_lo) * (W / 16) : 0;
     const int prev_chunks = 8 * rows * (W / 16);
+    // The pre-shifted copy runs sh7 bytes past its last row; when that row is the last
+    // row of the frame the final chunk is copied bytewise with a bounds check instead.
+    const bool tail_guard = SHIFTED && sh7 != 0 && cur_chunks > 0 && yc0 + r_hi == H;
+    if (tail_guard) cur_chunks -= 1;
     if (LAB_MODE == 1) {
         // lab: no global traffic
-    } else if (delta == 0) {
+    } else if (!SHIFTED && delta == 0) {
         for (int c = tid; c < cur_chunks; c += nthreads)
             *reinterpret_cast<uint4 *>(s_cur + (size_t)r_lo * W + (size_t)c * 16) =
                 *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
     } else {
         for (int c = tid; c < cur_chunks; c += nthreads) {
-            uint4 v = *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
-            v.x = sat_add_u8x4(v.x, delta); v.y = sat_add_u8x4(v.y, delta);
-            v.z = sat_add_u8x4(v.z, delta); v.w = sat_add_u8x4(v.w, delta);
+            uint4 v;  // 16-B load from a byte-aligned address (gfx950 handles unaligned global loads)
+            __builtin_memcpy(&v, g_cur + (size_t)c * 16, 16);
+            if (delta != 0) {
+                v.x = sat_add_u8x4(v.x, delta); v.y = sat_add_u8x4(v.y, delta);
+                v.z = sat_add_u8x4(v.z, delta); v.w = sat_add_u8x4(v.w, delta);
+            }
             *reinterpret_cast<uint4 *>(s_cur + (size_t)r_lo * W + (size_t)c * 16) = v;
         }
+        if (tail_guard && tid < 16 - sh7)
+            s_cur[(size_t)r_lo * W + (size_t)cur_chunks * 16 + tid] =
+                (uint8_t)clamp_u8((int)g_cur[(size_t)cur_chunks * 16 + tid] + delta);
     }
     if (LAB_MODE != 1)
     for (int c = tid; c < prev_chunks; c += nthreads)
@@ -120,9 +133,9 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     bool inside = true;
     int xs = 8 * bx;                              // LDS byte column of the window start
     if (SHIFTED) {
-        xs += px;
-        inside = xs >= 0 && xs + 16 <= W && 8 * brow >= r_lo && 8 * brow + 16 <= r_hi;
-        if (!inside) xs = 0;                      // keep the (ignored) reads in range
+        const int xf = 8 * bx + px;               // frame column of the window start
+        inside = xf >= 0 && xf + 16 <= W && 8 * brow >= r_lo && 8 * brow + 16 <= r_hi;
+        xs = inside ? xf - sh7 : 0;               // 8-aligned; ignored reads stay in range
     }
 
     // reference tile: 8 rows x 2 dwords, frame column 8*bx + 4
@@ -158,23 +171,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
 #pragma unroll
     for (int d = 0; d < DYG; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)((s0 + d) * 9 + 8); }
 
-    const int sh = SHIFTED ? (px & 3) : 0;
-    const uint8_t *win = s_cur + (size_t)(8 * brow + s0) * W + (SHIFTED ? (xs & ~3) : xs);
+    const uint8_t *win = s_cur + (size_t)(8 * brow + s0) * W + xs;
 #pragma unroll
     for (int s = 0; s < kRows; s++) {
-        uint32_t w0, w1, w2, w3;
-        if (SHIFTED) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(win + (size_t)s * W);
-            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
-            w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-            w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-            w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-            w3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-        } else {
-            const uint2 *p = reinterpret_cast<const uint2 *>(win + (size_t)s * W);
-            const uint2 a0 = p[0], a1 = p[1];
-            w0 = a0.x; w1 = a0.y; w2 = a1.x; w3 = a1.y;
-        }
+        const uint2 *p = reinterpret_cast<const uint2 *>(win + (size_t)s * W);
+        const uint2 a0 = p[0], a1 = p[1];
+        const uint32_t w0 = a0.x, w1 = a0.y, w2 = a1.x, w3 = a1.y;
         const u64 p01 = pack64(w0, w1), p12 = pack64(w1, w2), p23 = pack64(w2, w3);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
