@@ -20,6 +20,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxHist = 256;
+constexpr int kBatch = 10;  // record loads in flight per lane
 
 __device__ __forceinline__ void peak_window(int pos, int n, int *lo, int *hi)
 {
@@ -65,24 +66,39 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
     const uint8_t *subdirs = a.subdirs ? a.subdirs + pair * a.nblocks : nullptr;
     int s2x = 0, s2y = 0, cnt = 0;
     const int rounds = (a.nblocks + kThreads - 1) / kThreads;  // uniform trip count: ballots need every lane
-    for (int it = 0; it < rounds; it++) {
-        const int b = it * kThreads + (int)threadIdx.x;
-        bool ok = b < a.nblocks;
-        int vx = 0, vy = 0;
-        if (ok) {
-            const aof_block r = blocks[b];
-            ok = !(r.sad == AOF_SAD_SKIPPED || (int)r.sad >= a.value_threshold);
-            int hx = 0, hy = 0;
-            if (ok && subdirs) {
-                const int sd = subdirs[b];
-                hx = (sd == 0 || sd == 1 || sd == 7) ? 1 : ((sd == 3 || sd == 4 || sd == 5) ? -1 : 0);
-                hy = (sd == 1 || sd == 2 || sd == 3) ? 1 : ((sd == 5 || sd == 6 || sd == 7) ? -1 : 0);
-            }
-            vx = 2 * r.dx + hx; vy = 2 * r.dy + hy;
+    auto vote = [&](bool ok, aof_block r, int sd) {
+        ok = ok && !(r.sad == AOF_SAD_SKIPPED || (int)r.sad >= a.value_threshold);
+        int hx = 0, hy = 0;
+        if (ok && subdirs) {
+            hx = (sd == 0 || sd == 1 || sd == 7) ? 1 : ((sd == 3 || sd == 4 || sd == 5) ? -1 : 0);
+            hy = (sd == 1 || sd == 2 || sd == 3) ? 1 : ((sd == 5 || sd == 6 || sd == 7) ? -1 : 0);
         }
+        const int vx = 2 * r.dx + hx, vy = 2 * r.dy + hy;
         wave_vote(hist[0], vx + centre, ok);
         wave_vote(hist[1], vy + centre, ok);
         if (ok) { s2x += vx; s2y += vy; cnt++; }
+    };
+    for (int it0 = 0; it0 < rounds; it0 += kBatch) {
+        // issue a whole batch of independent coalesced loads before the first vote, so the
+        // pair's records arrive in one memory round trip instead of one per round
+        aof_block rec[kBatch];
+        int sdir[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int b = (it0 + k) * kThreads + (int)threadIdx.x;
+            rec[k].dx = 0; rec[k].dy = 0; rec[k].sad = AOF_SAD_SKIPPED;
+            sdir[k] = 8;
+            if (it0 + k < rounds && b < a.nblocks) {
+                rec[k] = blocks[b];
+                if (subdirs) sdir[k] = subdirs[b];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            if (it0 + k >= rounds) break;  // uniform
+            const int b = (it0 + k) * kThreads + (int)threadIdx.x;
+            vote(b < a.nblocks, rec[k], sdir[k]);
+        }
     }
     s2x = (int)wave_sum_u32((uint32_t)s2x);
     s2y = (int)wave_sum_u32((uint32_t)s2y);

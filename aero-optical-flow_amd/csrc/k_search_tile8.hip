@@ -35,6 +35,7 @@ constexpr int kLdsBudget = 80 * 1024;  // two workgroups per CU at the least
 #ifdef AOF_LAB  // experiment knobs of tools/k2_lab.hip; never defined in the product build
 int g_lab_rb = 0;           // force the strip height
 int g_lab_dyg = 0;          // force the dy group size (9 or 3)
+int g_lab_stagger = -1;     // first-generation stagger units (-1 = product default)
 __constant__ int c_lab_mode;  // 1: skip staging loads, 2: skip the search
 #define LAB_MODE c_lab_mode
 #else
@@ -53,9 +54,21 @@ __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)h
 // an LDS atomicMin on the packed key -- integer min, so still exactly first-minimum-wins.
 template <int DYG, bool SHIFTED>
 __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int rb, int nstrips,
-                                                              uint32_t total_wgs)
+                                                              uint32_t total_wgs, uint32_t first_gen,
+                                                              uint32_t stagger_units)
 {
     constexpr int NG = 9 / DYG;  // lanes per block
+    // De-phase the workgroups that share a CU.  Every workgroup costs the same, so the
+    // first generation (all slots filled at launch) would stage, search and retire in
+    // lock-step for the whole kernel, and the HBM latency of staging would never hide
+    // behind another workgroup's search (measured: +13 % kernel time).  A one-off
+    // pseudo-random delay of the first generation spreads the phases; later workgroups
+    // inherit the spread because they start whenever a slot frees.  Speed only.
+    if (blockIdx.x < first_gen && stagger_units) {
+        const uint32_t h = (blockIdx.x * 2654435761u) >> 16;
+        const uint32_t n = h % stagger_units;  // x ~1000 cycles
+        for (uint32_t i = 0; i < n; i++) __builtin_amdgcn_s_sleep(16);
+    }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const uint32_t logical = xcd_remap(blockIdx.x, total_wgs);
@@ -76,8 +89,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     const int r_lo = max(0, -yc0);                // valid LDS cur rows [r_lo, r_hi)
     const int r_hi = min(n_cur_rows, H - yc0);
     uint8_t *s_cur = smem;
-    uint8_t *s_prev = smem + (size_t)(8 * rb + 8) * W;
-    uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + (size_t)(16 * rb + 8) * W + 16);
+    uint8_t *s_prev = smem + (8 * rb + 8) * W;
+    uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + (16 * rb + 8) * W + 16);
     const int sh7 = SHIFTED ? (px & 7) : 0;        // floor-mod: px = 8*(px >> 3) + sh7
     const uint8_t *g_cur = a.cur + pair * a.pair_stride + (int64_t)(yc0 + r_lo) * W + sh7;
     const uint8_t *g_prev = a.prev + pair * a.pair_stride + (int64_t)(8 * by0 + 4) * W;
@@ -90,27 +103,26 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     if (LAB_MODE == 1) {
         // lab: no global traffic
     } else if (!SHIFTED && delta == 0) {
-        for (int c = tid; c < cur_chunks; c += nthreads)
-            *reinterpret_cast<uint4 *>(s_cur + (size_t)r_lo * W + (size_t)c * 16) =
-                *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
+        uint8_t *dst = s_cur + r_lo * W;
+        for (int o = tid * 16; o < cur_chunks * 16; o += nthreads * 16)
+            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(g_cur + o);
     } else {
         for (int c = tid; c < cur_chunks; c += nthreads) {
             uint4 v;  // 16-B load from a byte-aligned address (gfx950 handles unaligned global loads)
-            __builtin_memcpy(&v, g_cur + (size_t)c * 16, 16);
+            __builtin_memcpy(&v, g_cur + c * 16, 16);
             if (delta != 0) {
                 v.x = sat_add_u8x4(v.x, delta); v.y = sat_add_u8x4(v.y, delta);
                 v.z = sat_add_u8x4(v.z, delta); v.w = sat_add_u8x4(v.w, delta);
             }
-            *reinterpret_cast<uint4 *>(s_cur + (size_t)r_lo * W + (size_t)c * 16) = v;
+            *reinterpret_cast<uint4 *>(s_cur + r_lo * W + c * 16) = v;
         }
         if (tail_guard && tid < 16 - sh7)
-            s_cur[(size_t)r_lo * W + (size_t)cur_chunks * 16 + tid] =
-                (uint8_t)clamp_u8((int)g_cur[(size_t)cur_chunks * 16 + tid] + delta);
+            s_cur[r_lo * W + cur_chunks * 16 + tid] =
+                (uint8_t)clamp_u8((int)g_cur[cur_chunks * 16 + tid] + delta);
     }
     if (LAB_MODE != 1)
-    for (int c = tid; c < prev_chunks; c += nthreads)
-        *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) =
-            *reinterpret_cast<const uint4 *>(g_prev + (size_t)c * 16);
+    for (int o = tid * 16; o < prev_chunks * 16; o += nthreads * 16)
+        *reinterpret_cast<uint4 *>(s_prev + o) = *reinterpret_cast<const uint4 *>(g_prev + o);
     if (NG > 1)
         for (int b = tid; b < rows * nx; b += nthreads) s_best[b] = 0xFFFFFFFFu;
     __syncthreads();
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     const int nblk = rows * nx;
     const bool live = tid < nblk * NG;
     if (NG == 1 && !live) return;
-    const int grp = live ? tid / nblk : 0, blk = live ? tid - grp * nblk : 0;
+    const int grp = (NG > 1 && live) ? tid / nblk : 0, blk = live ? tid - grp * nblk : 0;
     const int brow = blk / nx, bx = blk % nx;
     constexpr int kRows = DYG + 7;                // search rows this lane streams
     const int s0 = grp * DYG;                     // first dy index of the group
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t *p =
-            reinterpret_cast<const uint32_t *>(s_prev + (size_t)(8 * brow + r) * W + 8 * bx + 4);
+            reinterpret_cast<const uint32_t *>(s_prev + (8 * brow + r) * W + 8 * bx + 4);
         ref[r][0] = p[0];
         ref[r][1] = p[1];
     }
@@ -171,10 +183,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
 #pragma unroll
     for (int d = 0; d < DYG; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)((s0 + d) * 9 + 8); }
 
-    const uint8_t *win = s_cur + (size_t)(8 * brow + s0) * W + xs;
+    const uint8_t *win = s_cur + (8 * brow + s0) * W + xs;
 #pragma unroll
     for (int s = 0; s < kRows; s++) {
-        const uint2 *p = reinterpret_cast<const uint2 *>(win + (size_t)s * W);
+        const uint2 *p = reinterpret_cast<const uint2 *>(win + s * W);
         const uint2 a0 = p[0], a1 = p[1];
         const uint32_t w0 = a0.x, w1 = a0.y, w2 = a1.x, w3 = a1.y;
         const u64 p01 = pack64(w0, w1), p12 = pack64(w1, w2), p23 = pack64(w2, w3);
@@ -278,7 +290,7 @@ int launch_search_tile8(const SearchArgs &a, void *stream)
     const int64_t total = a.n_pairs * p.nstrips;
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    void (*fn)(SearchArgs, int, int, uint32_t);
+    void (*fn)(SearchArgs, int, int, uint32_t, uint32_t, uint32_t);
     if (p.dyg == 9) fn = a.pred ? k_search_tile8<9, true> : k_search_tile8<9, false>;
     else fn = a.pred ? k_search_tile8<3, true> : k_search_tile8<3, false>;
     if (p.lds > 64 * 1024) {  // beyond the default dynamic-LDS window
@@ -286,8 +298,17 @@ int launch_search_tile8(const SearchArgs &a, void *stream)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         if (e != hipSuccess) return (int)e;
     }
+    // first generation = workgroups resident at launch (LDS- or register-limited), 256 CUs
+    int per_cu = (int)((160 * 1024) / p.lds);
+    const int by_regs = 2048 / p.threads;  // 128 VGPRs -> 4 waves per SIMD = 16 waves per CU
+    if (per_cu > by_regs) per_cu = by_regs;
+    if (per_cu < 1) per_cu = 1;
+    uint32_t first_gen = 256u * (uint32_t)per_cu, stagger = 24;
+#ifdef AOF_LAB
+    if (g_lab_stagger >= 0) stagger = (uint32_t)g_lab_stagger;
+#endif
     hipLaunchKernelGGL(fn, dim3((uint32_t)total), dim3(p.threads), p.lds, s, a, p.rb, p.nstrips,
-                       (uint32_t)total);
+                       (uint32_t)total, first_gen, stagger);
     return (int)hipGetLastError();
 }
 

@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one rank per GPU); gloo = rehearsal of the N>1 "
+                         "control flow with several ranks sharing the GPUs that exist")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,20 +103,24 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     aof = ge.load_package()
     import importlib
     batch = importlib.import_module(ge.PKG_NAME + ".batch")
     desc, W, H, over, reach = WORKLOADS[args.workload]
     p = aof.default_params(W, H, **over)
-    eng = aof.FlowEngine(p, local_rank)
+    eng = aof.FlowEngine(p, dev_index)
     n = args.pairs
     prev, cur, shifts = make_batch_gpu(W, H, n, reach, 0xA0F + 7919 * rank, device,
                                        brightness=9 if p.mean_subtract else 0)
@@ -126,7 +133,11 @@ def main():
     def step():
         eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
         # the only exchange of the batched mode: 16 B per pair, every rank gets all flows
-        return batch.gather_flows(flows, world * n) if world > 1 else flows
+        if world == 1:
+            return flows
+        if args.backend == "gloo":  # rehearsal only: gloo gathers host copies
+            return batch.gather_flows(flows.cpu(), world * n)
+        return batch.gather_flows(flows, world * n)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -145,7 +156,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -181,7 +192,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_gpu": n, "global_pairs": world * n,
-                   "search_kernel": eng.variant, "parallelism": f"pairs sharded x{world}, flows all_gather"
+                   "search_kernel": eng.variant, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

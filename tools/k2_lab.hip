@@ -54,9 +54,12 @@ int main(int argc, char **argv)
     const double alg = (2.0 * frame + 4.0 * g.blocks() + 16) * n;
     printf("pairs %d  blocks/pair %d\n", n, g.blocks());
     printf("%4s %8s %6s %10s %10s %10s %8s\n", "rb", "threads", "lds_KB", "full_ms", "nostage_ms", "nosearch_ms", "roof%");
-    for (int dyg : {9, 3})
+    const int only_rb = argc > 2 ? atoi(argv[2]) : 0;
+    for (int stag : {0, 8, 16, 24, 32, 48})
+    for (int dyg : {9})
     for (int rb = 1; rb <= 6; rb++) {
-        g_lab_rb = rb; g_lab_dyg = dyg;
+        if (only_rb && rb != only_rb) continue;
+        g_lab_rb = rb; g_lab_dyg = dyg; g_lab_stagger = stag;
         Tile8Plan pl = plan_tile8(a);
         if (!pl.rb) continue;
         float t[3];
@@ -64,7 +67,7 @@ int main(int argc, char **argv)
             CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lab_mode), &mode, sizeof(int)));
             t[mode] = time_launch(a, 9);
         }
-        printf("dyg%d %4d %8d %6.1f %10.4f %10.4f %10.4f %8.2f\n", dyg, rb, pl.threads, pl.lds / 1024.0, t[0], t[1], t[2],
+        printf("stag%-3d dyg%d %4d %8d %6.1f %10.4f %10.4f %10.4f %8.2f\n", stag, dyg, rb, pl.threads, pl.lds / 1024.0, t[0], t[1], t[2],
                100.0 * alg / (t[0] * 1e-3) / 8e12);
     }
     return 0;
