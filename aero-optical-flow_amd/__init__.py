@@ -48,7 +48,7 @@ class Params(C.Structure):
 class WsLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "sums", "l1_prev", "l1_cur", "l1_blocks", "l1_subdirs", "l1_flows",
-        "l0_blocks", "l0_subdirs")]
+        "l0_blocks", "l0_subdirs", "l0_hist", "l1_hist")]
 
 
 class AofError(RuntimeError):

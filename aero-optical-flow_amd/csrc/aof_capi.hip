@@ -93,14 +93,24 @@ SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const
     a.subpixel = p.subpixel;
     a.blocks = blocks; a.subdirs = p.subpixel ? subdirs : nullptr;
     a.pred = pred; a.sums = sums; a.level = level; a.n_pairs = n;
+    a.hist_parts = nullptr; a.hist_range = level_range(p, level);
     return a;
 }
 
-int run_search(aof_ctx *ctx, const SearchArgs &a, hipStream_t s)
+// Runs the level's search; *parts_used says whether the kernel wrote per-strip histograms
+// into `parts` (only the tile8 kernel does), in which case K3 sums those instead of the records.
+int run_search(aof_ctx *ctx, SearchArgs a, uint32_t *parts, const uint32_t **parts_used, int *nstrips,
+               hipStream_t s)
 {
     int rc;
-    if (!ctx->force_generic && tile8_supported(a)) rc = launch_search_tile8(a, s);
-    else if (!ctx->force_generic && tile16_supported(a)) rc = launch_search_tile16(a, s);
+    *parts_used = nullptr;
+    *nstrips = 0;
+    if (!ctx->force_generic && tile8_supported(a)) {
+        a.hist_parts = parts;
+        *parts_used = parts;
+        *nstrips = plan_tile8(a.w, a.grid.nx, a.grid.ny).nstrips;
+        rc = launch_search_tile8(a, s);
+    } else if (!ctx->force_generic && tile16_supported(a)) rc = launch_search_tile16(a, s);
     else rc = launch_search_generic(a, s);
     if (rc) return fail(ctx, -EIO, "search launch: %s", hipGetErrorString((hipError_t)rc));
     return 0;
@@ -267,6 +277,8 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         if (rc) return fail(ctx, -EIO, "pyramid launch: %s", hipGetErrorString((hipError_t)rc));
     }
     const aof_flow *pred = nullptr;
+    const uint32_t *parts = nullptr;
+    int nstrips = 0;
     if (two) {
         aof_block *blocks1 = reinterpret_cast<aof_block *>(ws + L.l1_blocks);
         uint8_t *subdirs1 = p.subpixel ? ws + L.l1_subdirs : nullptr;
@@ -276,11 +288,12 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
             SearchArgs a = search_args(ctx, 1, ws + L.l1_prev, ws + L.l1_cur, l1_stride, blocks1,
                                        subdirs1, nullptr, sums, n_pairs);
             Timed t(ctx, AOF_K_SEARCH_L1, s);
-            rc = run_search(ctx, a, s);
+            rc = run_search(ctx, a, reinterpret_cast<uint32_t *>(ws + L.l1_hist), &parts, &nstrips, s);
             if (rc) return rc;
         }
         {
             ReduceArgs r;
+            r.parts = parts; r.nstrips = nstrips;
             r.blocks = blocks1; r.subdirs = subdirs1; r.nblocks = ctx->g1.blocks();
             r.range = level_range(p, 1); r.value_threshold = value_threshold_u16(p);
             r.hist_filter = p.hist_filter; r.min_valid = p.min_valid;
@@ -295,11 +308,12 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         SearchArgs a = search_args(ctx, 0, d_prev, d_cur, pair_stride, blocks0, subdirs0, pred, sums,
                                    n_pairs);
         Timed t(ctx, AOF_K_SEARCH, s);
-        rc = run_search(ctx, a, s);
+        rc = run_search(ctx, a, reinterpret_cast<uint32_t *>(ws + L.l0_hist), &parts, &nstrips, s);
         if (rc) return rc;
     }
     {
         ReduceArgs r;
+        r.parts = parts; r.nstrips = nstrips;
         r.blocks = blocks0; r.subdirs = subdirs0; r.nblocks = ctx->g0.blocks();
         r.range = level_range(p, 0); r.value_threshold = value_threshold_u16(p);
         r.hist_filter = p.hist_filter; r.min_valid = p.min_valid;

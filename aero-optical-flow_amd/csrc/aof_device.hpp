@@ -65,6 +65,22 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
+// Adds one vote per active lane to hist[bin] (LDS): neighbouring blocks mostly vote for
+// the SAME bin, which would serialise a per-lane LDS atomic 64 ways, so equal bins are
+// first aggregated across the wave (ballot) and one lane adds the count.  Must be called
+// by every lane of the wave.
+__device__ __forceinline__ void wave_vote(uint32_t *hist, int bin, bool active)
+{
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bin, leader, 64);
+        const unsigned long long same = __ballot(active && bin == b) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 // Bijective XCD-aware remap of a 1-D grid (workgroups b and b+8 share an XCD's
 // L2 under round-robin placement): XCD k gets one contiguous chunk of logical
 // ids, so consecutive strips of one frame pair are staged through the same L2.

@@ -20,7 +20,15 @@ struct Grid {
     AOF_HD int32_t blocks() const { return nx * ny; }
 };
 
+// Strip plan of the tile8 search kernel: rb block rows per workgroup.
+struct Tile8Plan {
+    int rb, threads, nstrips, dyg;
+    size_t lds;
+};
+
 // Host-only parameter logic (aof_params.cpp).
+Tile8Plan plan_tile8(int w, int nx, int ny);   // rb == 0: no feasible plan
+bool tile8_geometry(const aof_params &p, int level);  // level can run the tile8 kernel
 int grid_for_level(const aof_params &p, int level, Grid *g);
 int level_range(const aof_params &p, int level);  // histogram half-range R
 int value_threshold_u16(const aof_params &p);     // SAD gate clamped to the u16 record
@@ -42,6 +50,8 @@ struct SearchArgs {
     const uint32_t *sums;      // [n_pairs][2][2] pixel sums, or nullptr when not equalising
     int32_t level;             // which sums column to use
     int64_t n_pairs;
+    uint32_t *hist_parts;      // tile8 only: [n_pairs][nstrips][2][2*(2R+1)+1] per-strip vote histograms
+    int32_t hist_range;        // R
 };
 
 struct ReduceArgs {
@@ -56,6 +66,8 @@ struct ReduceArgs {
     const aof_flow *pred;      // copy pred_x/pred_y + PRED_VALID from here (level 0 of two), or nullptr
     int32_t emit_predictor;    // level 1: write the integer predictor into pred_x/pred_y
     int64_t n_pairs;
+    const uint32_t *parts;     // per-strip histograms written by the tile8 search (then blocks are not read)
+    int32_t nstrips;
 };
 
 struct PyramidArgs {

@@ -42,6 +42,53 @@ int value_threshold_u16(const aof_params &p)
     return p.value_threshold > 0xFFFF ? 0xFFFF : p.value_threshold;
 }
 
+#ifdef AOF_LAB  // experiment knobs of tools/k2_lab.hip; never defined in the product build
+int g_lab_rb = 0, g_lab_dyg = 0;
+#endif
+
+// Pick the strip height that keeps most lanes busy over the whole frame.  Workgroups
+// are whole multiples of 256 threads (one wave per SIMD): measured on MI355X, a
+// 5-wave workgroup with better lane use (rb=4 at VGA, 97 %) ran 33 % slower than the
+// 4-wave one (rb=3, 91 %) because fewer workgroups fit a CU and staging stops
+// overlapping with the search (profiles/r01_b_k2_lab.txt).  One lane per block
+// (dyg = 9): three lanes per block measured 11 % slower (profiles/r01_c_k2_lab_dyg.txt).
+Tile8Plan plan_tile8(int w, int nx, int ny)
+{
+    const int kMaxThreads = 512;
+    const size_t kLdsBudget = 80 * 1024;  // two workgroups per CU at the least
+    Tile8Plan best = {0, 0, 0, 0, 0};
+    double best_eff = -1.0;
+    int dyg = 9;
+#ifdef AOF_LAB
+    if (g_lab_dyg) dyg = g_lab_dyg;
+#endif
+    for (int rb = 1; rb <= 16; rb++) {
+        const int items = rb * nx * (9 / dyg);
+        int threads = (items + 255) / 256 * 256;
+#ifdef AOF_LAB
+        if (g_lab_rb && rb != g_lab_rb) continue;
+        if (g_lab_rb) threads = (items + 63) / 64 * 64;
+#endif
+        // cur rows + prev rows + 16 pad, per-block best keys, vote histograms (<= 2*104 bins)
+        const size_t lds = (size_t)(16 * rb + 8) * w + 16 + 4 * (size_t)(rb * nx) + 4 * 2 * 104;
+        if (threads > kMaxThreads || lds > kLdsBudget) break;
+        const int nstrips = (ny + rb - 1) / rb;
+        const double eff = (double)nx * ny * (9 / dyg) / ((double)nstrips * threads);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = {rb, threads, nstrips, dyg, lds}; }
+    }
+    return best;
+}
+
+bool tile8_geometry(const aof_params &p, int level)
+{
+    if (p.tile != 8 || p.search != 4 || p.subpixel || p.grid_mode != AOF_GRID_DENSE) return false;
+    const int w = p.width >> level;
+    if (w % 16) return false;
+    Grid g;
+    if (grid_for_level(p, level, &g)) return false;
+    return plan_tile8(w, g.nx, g.ny).rb > 0;
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace aof
@@ -156,6 +203,17 @@ int aof_workspace_layout(const aof_params *p, int64_t n_pairs, aof_ws_layout *ou
     out->l1_flows = off;    off = align_up(off + (two ? n * sizeof(aof_flow) : 0), 256);
     out->l0_blocks = off;   off = align_up(off + n * (size_t)g0.blocks() * sizeof(aof_block), 256);
     out->l0_subdirs = off;  off = align_up(off + n * (size_t)g0.blocks(), 256);
+    for (int level = 0; level < p->pyramid_levels; level++) {
+        size_t bytes = 0;
+        if (tile8_geometry(*p, level)) {
+            const Grid &g = level ? g1 : g0;
+            const Tile8Plan pl = plan_tile8(p->width >> level, g.nx, g.ny);
+            const size_t bins = 2 * (2 * (size_t)level_range(*p, level) + 1) + 1;
+            bytes = n * (size_t)pl.nstrips * 2 * bins * sizeof(uint32_t);
+        }
+        (level ? out->l1_hist : out->l0_hist) = off;
+        off = align_up(off + bytes, 256);
+    }
     out->total_bytes = off ? off : 256;
     return 0;
 }

@@ -39,19 +39,6 @@ __device__ __forceinline__ long long floor_div(long long a, long long b)
     return q;
 }
 
-// Adds one vote per active lane to hist[bin]: one LDS atomic per distinct bin in the wave.
-__device__ __forceinline__ void wave_vote(uint32_t *hist, int bin, bool active)
-{
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int b = __shfl(bin, leader, 64);
-        const unsigned long long same = __ballot(active && bin == b) & todo;
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], (uint32_t)__popcll(same));
-        todo &= ~same;
-    }
-}
-
 __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
 {
     __shared__ uint32_t hist[2][kMaxHist];
@@ -62,6 +49,22 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
     if (threadIdx.x < 3) sums[threadIdx.x] = 0;
     __syncthreads();
 
+    if (a.parts) {
+        // The tile8 search already voted per strip: sum the strips' histograms.  Count and
+        // shift sums follow from the histogram: count = sum h[k], sum2 = sum (k - centre) h[k].
+        const uint32_t *parts = a.parts + (size_t)pair * a.nstrips * (size_t)(2 * n);
+        for (int k = threadIdx.x; k < 2 * n; k += kThreads) {
+            uint32_t v = 0;
+            for (int st = 0; st < a.nstrips; st++) v += parts[(size_t)st * (2 * n) + k];
+            const int axis = k >= n, bin = k - axis * n;
+            hist[axis][bin] = v;
+            if (v) {
+                atomicAdd(&sums[axis], (bin - centre) * (int)v);
+                if (!axis) atomicAdd(&sums[2], (int)v);
+            }
+        }
+        __syncthreads();
+    } else {
     const aof_block *blocks = a.blocks + pair * a.nblocks;
     const uint8_t *subdirs = a.subdirs ? a.subdirs + pair * a.nblocks : nullptr;
     int s2x = 0, s2y = 0, cnt = 0;
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
         atomicAdd(&sums[2], cnt);
     }
     __syncthreads();
+    }
     if (threadIdx.x != 0) return;
     {
 #pragma clang fp contract(off)

@@ -30,11 +30,8 @@ namespace aof {
 namespace {
 
 constexpr int kMaxThreads = 512;
-constexpr int kLdsBudget = 80 * 1024;  // two workgroups per CU at the least
 
 #ifdef AOF_LAB  // experiment knobs of tools/k2_lab.hip; never defined in the product build
-int g_lab_rb = 0;           // force the strip height
-int g_lab_dyg = 0;          // force the dy group size (9 or 3)
 int g_lab_stagger = -1;     // first-generation stagger units (-1 = product default)
 __constant__ int c_lab_mode;  // 1: skip staging loads, 2: skip the search
 #define LAB_MODE c_lab_mode
@@ -91,6 +88,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     uint8_t *s_cur = smem;
     uint8_t *s_prev = smem + (8 * rb + 8) * W;
     uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + (16 * rb + 8) * W + 16);
+    uint32_t *s_hist = s_best + rb * nx;            // [2][bins] votes of this strip
+    const int centre = 2 * a.hist_range + 1, bins = 2 * centre + 1;
     const int sh7 = SHIFTED ? (px & 7) : 0;        // floor-mod: px = 8*(px >> 3) + sh7
     const uint8_t *g_cur = a.cur + pair * a.pair_stride + (int64_t)(yc0 + r_lo) * W + sh7;
     const uint8_t *g_prev = a.prev + pair * a.pair_stride + (int64_t)(8 * by0 + 4) * W;
@@ -125,6 +124,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         *reinterpret_cast<uint4 *>(s_prev + o) = *reinterpret_cast<const uint4 *>(g_prev + o);
     if (NG > 1)
         for (int b = tid; b < rows * nx; b += nthreads) s_best[b] = 0xFFFFFFFFu;
+    if (a.hist_parts)
+        for (int k = tid; k < 2 * bins; k += nthreads) s_hist[k] = 0;
     __syncthreads();
     if (LAB_MODE == 2) {
         if (tid < rows * nx) {
@@ -137,7 +138,6 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     // ---- one (block, dy group) per lane; group-major so that group 0 = lanes [0, rows*nx) ----
     const int nblk = rows * nx;
     const bool live = tid < nblk * NG;
-    if (NG == 1 && !live) return;
     const int grp = (NG > 1 && live) ? tid / nblk : 0, blk = live ? tid - grp * nblk : 0;
     const int brow = blk / nx, bx = blk % nx;
     constexpr int kRows = DYG + 7;                // search rows this lane streams
@@ -150,6 +150,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         xs = inside ? xf - sh7 : 0;               // 8-aligned; ignored reads stay in range
     }
 
+    uint32_t diff = 0, best = 0xFFFFFFFFu;
+    // whole waves beyond the strip's blocks skip the search (wave-uniform) but still
+    // reach the barriers and the vote below
+    if ((tid & ~63) < nblk * NG) {
     // reference tile: 8 rows x 2 dwords, frame column 8*bx + 4
     uint32_t ref[8][2];
 #pragma unroll
@@ -161,7 +165,6 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     }
 
     // 4x4 gradient gate on tile bytes [2..5] x rows [2..5]
-    uint32_t diff = 0;
     {
         uint32_t mid[4];
 #pragma unroll
@@ -204,7 +207,6 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     }
 
     // arg-min over the 81 packed keys, scan order = key order
-    uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
     for (int d = 0; d < DYG; d++) {
         const uint32_t base = (uint32_t)((s0 + d) * 9);
@@ -218,13 +220,14 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         best = min(best, min(min(k3, k4), k5));
         best = min(best, min(min(k6, k7), acc_8[d]));
     }
+    }  // wave has live lanes
 
     if (NG > 1) {
         if (live) atomicMin(&s_best[blk], best);
         __syncthreads();
-        if (!live || grp != 0) return;
         best = s_best[blk];
     }
+    const bool writer = live && grp == 0;        // one lane per block
     aof_block rec;
     rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
     if (inside && diff >= (uint32_t)a.feature_threshold) {
@@ -233,41 +236,18 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         rec.dy = (int8_t)(py + idx / 9 - 4);
         rec.sad = (uint16_t)(best >> 16);
     }
-    a.blocks[pair * (int64_t)(nx * ny) + (int64_t)(by0 + brow) * nx + bx] = rec;
-}
+    if (writer) a.blocks[pair * (int64_t)(nx * ny) + (int64_t)(by0 + brow) * nx + bx] = rec;
 
-struct Tile8Plan { int rb, threads, nstrips, dyg; size_t lds; };
-
-Tile8Plan plan_tile8(const SearchArgs &a)
-{
-    // Pick the strip height that keeps most lanes busy over the whole frame.  Workgroups
-    // are whole multiples of 256 threads (one wave per SIMD): measured on MI355X, a
-    // 5-wave workgroup with better lane use (rb=4 at VGA, 97 %) ran 33 % slower than the
-    // 4-wave one (rb=3, 91 %) because fewer workgroups fit a CU and staging stops
-    // overlapping with the search (profiles/r01_b_k2_lab.txt).
-    Tile8Plan best = {0, 0, 0, 0, 0};
-    double best_eff = -1.0;
-    int dyg = 9;  // measured: 3 lanes per block (dyg = 3) is 11 % slower at VGA (profiles/r01_c_k2_lab_dyg.txt)
-#ifdef AOF_LAB
-    if (g_lab_dyg) dyg = g_lab_dyg;
-#endif
-    for (int rb = 1; rb <= 16; rb++) {
-#ifdef AOF_LAB
-        if (g_lab_rb && rb != g_lab_rb) continue;
-#endif
-        const int items = rb * a.grid.nx * (9 / dyg);
-#ifdef AOF_LAB
-        const int threads = g_lab_rb ? (items + 63) / 64 * 64 : (items + 255) / 256 * 256;
-#else
-        const int threads = (items + 255) / 256 * 256;
-#endif
-        const size_t lds = (size_t)(16 * rb + 8) * a.w + 16 + 4 * (size_t)(rb * a.grid.nx);
-        if (threads > kMaxThreads || lds > (size_t)kLdsBudget) break;
-        const int nstrips = (a.grid.ny + rb - 1) / rb;
-        const double eff = (double)a.grid.blocks() * (9 / dyg) / ((double)nstrips * threads);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = {rb, threads, nstrips, dyg, lds}; }
+    // Votes of this strip's accepted blocks, so that K3 sums nstrips small histograms per
+    // pair instead of re-reading every record (DESIGN.md "Kernels": K3).
+    if (a.hist_parts) {
+        const bool ok = writer && rec.sad != AOF_SAD_SKIPPED && (int)rec.sad < a.value_threshold;
+        wave_vote(s_hist, 2 * rec.dx + centre, ok);
+        wave_vote(s_hist + bins, 2 * rec.dy + centre, ok);
+        __syncthreads();
+        uint32_t *out = a.hist_parts + ((size_t)pair * nstrips + strip) * (size_t)(2 * bins);
+        for (int k = tid; k < 2 * bins; k += nthreads) out[k] = s_hist[k];
     }
-    return best;
 }
 
 }  // namespace
@@ -279,13 +259,13 @@ bool tile8_supported(const SearchArgs &a)
     if (a.w % 16 || a.pair_stride % 16) return false;
     if (reinterpret_cast<uintptr_t>(a.prev) % 16 || reinterpret_cast<uintptr_t>(a.cur) % 16) return false;
     if ((int64_t)a.w * a.h > 0x7FFFFFFF) return false;
-    return plan_tile8(a).rb > 0;
+    return plan_tile8(a.w, a.grid.nx, a.grid.ny).rb > 0;
 }
 
 int launch_search_tile8(const SearchArgs &a, void *stream)
 {
     if (a.n_pairs == 0) return 0;
-    const Tile8Plan p = plan_tile8(a);
+    const Tile8Plan p = plan_tile8(a.w, a.grid.nx, a.grid.ny);
     if (p.rb == 0) return (int)hipErrorInvalidValue;
     const int64_t total = a.n_pairs * p.nstrips;
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;

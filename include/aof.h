@@ -86,6 +86,8 @@ typedef struct aof_ws_layout {
     size_t l1_flows;  /* aof_flow [n_pairs] (pred_x/pred_y = predictor) */
     size_t l0_blocks; /* aof_block [n_pairs][nb0] when the caller passes none */
     size_t l0_subdirs;/* u8 [n_pairs][nb0] when the caller passes none */
+    size_t l0_hist;   /* u32 [n_pairs][strips0][2][bins0]: per-strip vote histograms (tile8 kernel) */
+    size_t l1_hist;   /* u32 [n_pairs][strips1][2][bins1] */
 } aof_ws_layout;
 
 typedef struct aof_ctx aof_ctx;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+namespace aof { extern int g_lab_rb, g_lab_dyg; }
 #include "../aero-optical-flow_amd/csrc/k_search_tile8.hip"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
@@ -50,7 +51,7 @@ int main(int argc, char **argv)
     a.prev = d_prev; a.cur = d_cur; a.pair_stride = (int64_t)frame; a.w = W; a.h = H;
     a.tile = 8; a.search = 4; a.grid = g; a.feature_threshold = 30; a.value_threshold = 3000;
     a.subpixel = 0; a.blocks = d_blocks; a.subdirs = nullptr; a.pred = nullptr; a.sums = nullptr;
-    a.level = 0; a.n_pairs = n;
+    a.level = 0; a.n_pairs = n; a.hist_parts = nullptr; a.hist_range = 4;
     const double alg = (2.0 * frame + 4.0 * g.blocks() + 16) * n;
     printf("pairs %d  blocks/pair %d\n", n, g.blocks());
     printf("%4s %8s %6s %10s %10s %10s %8s\n", "rb", "threads", "lds_KB", "full_ms", "nostage_ms", "nosearch_ms", "roof%");
@@ -60,7 +61,7 @@ int main(int argc, char **argv)
     for (int rb = 1; rb <= 6; rb++) {
         if (only_rb && rb != only_rb) continue;
         g_lab_rb = rb; g_lab_dyg = dyg; g_lab_stagger = stag;
-        Tile8Plan pl = plan_tile8(a);
+        Tile8Plan pl = plan_tile8(a.w, a.grid.nx, a.grid.ny);
         if (!pl.rb) continue;
         float t[3];
         for (int mode = 0; mode < 3; mode++) {
