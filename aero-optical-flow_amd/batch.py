@@ -20,6 +20,38 @@ def gather_flows(local_flows, n_total: int, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local_flows
+    return gather_flows_async(local_flows, n_total, group).wait()
+
+
+class PendingGather:
+    """An all_gather of flow records in flight (see gather_flows_async)."""
+
+    def __init__(self, work, out, n_total, width, world):
+        self.work, self.out, self.n_total, self.width, self.world = work, out, n_total, width, world
+
+    def wait(self):
+        """Blocks the CURRENT STREAM (not the host, on GPUs) until the records have landed
+        and returns them as [n_total, 16] in pair order."""
+        import torch
+        if self.work is not None:
+            self.work.wait()
+        if self.n_total == self.world * self.width:
+            return self.out
+        parts = []
+        for r in range(self.world):
+            rb, re_ = shard_range(self.n_total, r, self.world)
+            parts.append(self.out[r * self.width:r * self.width + (re_ - rb)])
+        return torch.cat(parts, dim=0)
+
+
+def gather_flows_async(local_flows, n_total: int, group=None) -> PendingGather:
+    """Starts the gather and returns at once, so the next batch's search can be enqueued
+    while the 16-byte records cross xGMI (the collective runs on RCCL's own stream).
+    `local_flows` must stay untouched until wait() -- alternate two buffers."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return PendingGather(None, local_flows, n_total, n_total, 1)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     b, e = shard_range(n_total, rank, world)
     assert local_flows.shape[0] == e - b and local_flows.shape[1] == 16
@@ -29,11 +61,5 @@ def gather_flows(local_flows, n_total: int, group=None):
         padded = torch.zeros((width, 16), dtype=torch.uint8, device=local_flows.device)
         padded[:e - b] = local_flows
     out = torch.empty((world * width, 16), dtype=torch.uint8, device=local_flows.device)
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
-    if n_total == world * width:
-        return out
-    parts = []
-    for r in range(world):
-        rb, re_ = shard_range(n_total, r, world)
-        parts.append(out[r * width:r * width + (re_ - rb)])
-    return torch.cat(parts, dim=0)
+    work = dist.all_gather_into_tensor(out, padded.contiguous(), group=group, async_op=True)
+    return PendingGather(work, out, n_total, width, world)

@@ -126,20 +126,34 @@ def main():
                                        brightness=9 if p.mean_subtract else 0)
     nb = eng.nblocks(0)
     blocks = torch.empty((n, nb), dtype=torch.int32, device=device)
-    flows = torch.empty((n, 16), dtype=torch.uint8, device=device)
+    flows2 = [torch.empty((n, 16), dtype=torch.uint8, device=device) for _ in range(2)]
+    flows = flows2[0]
     L = aof.workspace_layout(p, n)
     ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=device)
 
+    state = {"i": 0, "pending": None, "gathered": None}
+
     def step():
-        eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
-        # the only exchange of the batched mode: 16 B per pair, every rank gets all flows
+        # Two flow buffers alternate so that the gather of step i (the only exchange of the
+        # batched mode: 16 B per pair, every rank gets all flows) crosses xGMI on RCCL's
+        # stream while step i+1's search is already enqueued.
+        f = flows2[state["i"] & 1]
+        state["i"] += 1
+        eng.flow_batch(prev, cur, blocks=blocks, flows=f, workspace=ws)
         if world == 1:
-            return flows
-        if args.backend == "gloo":  # rehearsal only: gloo gathers host copies
-            return batch.gather_flows(flows.cpu(), world * n)
-        return batch.gather_flows(flows, world * n)
+            return
+        if state["pending"] is not None:
+            state["gathered"] = state["pending"].wait()
+        src = f.cpu() if args.backend == "gloo" else f  # gloo (rehearsal) gathers host copies
+        state["pending"] = batch.gather_flows_async(src, world * n)
+
+    def drain():
+        if state["pending"] is not None:
+            state["gathered"] = state["pending"].wait()
+            state["pending"] = None
 
     def fence():
+        drain()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -206,12 +220,13 @@ def main():
     if rank == 0:
         from oracle import pyoracle as orc
         po = orc.params_from(p)
-        gb, gf = aof.blocks_view(blocks[:4]), aof.flows_view(flows[:4])
+        gb, gf = aof.blocks_view(blocks[:4]), aof.flows_view(flows2[(state["i"] - 1) & 1][:4])
         hp, hc = prev[:4].cpu().numpy(), cur[:4].cpu().numpy()
         ok = True
         for i in range(4):
             ref = orc.flow_pair(po, hp[i], hc[i])
             ok &= gb[i].tobytes() == ref["blocks"].tobytes() and gf[i].tobytes() == ref["flow"].tobytes()
+        flows = flows2[(state["i"] - 1) & 1]
         fl = aof.flows_view(flows)
         known = bool(np.array_equal(fl["flow_x"], shifts[:, 0].astype(np.float32)) and
                      np.array_equal(fl["flow_y"], shifts[:, 1].astype(np.float32)))

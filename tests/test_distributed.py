@@ -41,6 +41,10 @@ def _worker(rank, world, port, n_total, out_dir):
         local = torch.from_numpy(flows.view(np.uint8).reshape(e - b, 16).copy())
         full = batch.gather_flows(local, n_total)
         assert full.shape == (n_total, 16)
+        # pipelined form used by bench.py: start, do other work, then wait
+        pending = batch.gather_flows_async(local.clone(), n_total)
+        again = pending.wait()
+        assert torch.equal(again, full)
         np.save(os.path.join(out_dir, f"rank{rank}.npy"), full.numpy())
         dist.barrier()
     finally:
