@@ -45,6 +45,11 @@ class Params(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class IngestParams(C.Structure):
+    """``aof_ingest_params`` (include/aof.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("camera_width", "camera_height", "crop_width", "crop_height")]
+
+
 class WsLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "sums", "l1_prev", "l1_cur", "l1_blocks", "l1_subdirs", "l1_flows",
@@ -86,6 +91,9 @@ def _load():
         "aof_flow_pair_host": (C.c_int, [VP, VP, VP, VP, VP, VP]),
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
         "aof_stream_reset": (C.c_int, [VP]),
+        "aof_ingest_batch_device": (C.c_int, [P(IngestParams), VP, I64, I64, VP, I64, VP, VP]),
+        "aof_exposure_msv": (C.c_float, [VP]),
+        "aof_exposure_bin": (C.c_int, [C.c_int]),
         "aof_set_profiling": (C.c_int, [VP, C.c_int]),
         "aof_kernel_ms": (C.c_int, [VP, C.c_int, P(C.c_float)]),
         "aof_profile_count": (C.c_int, [VP, C.c_int]),
@@ -150,6 +158,32 @@ def algorithmic_bytes(p: Params) -> int:
 def abs_diffs(p: Params) -> int:
     _, _, _, _, nx, ny = grid(p, 0)
     return nx * ny * (2 * p.search + 1) ** 2 * p.tile ** 2
+
+
+def ingest_batch(camera, crop_w, crop_h, cropped=None, hist=None, want_hist=True):
+    """Frame ingest on the device (centre crop + 10-bin exposure histogram; the caller-side
+    steps of /root/reference/src/mainloop.cpp:295-298,203-214).  camera: uint8 CUDA tensor
+    [n, cam_h, cam_w].  Returns (cropped [n, crop_h, crop_w], hist [n, 10] int32-as-uint32)."""
+    import torch
+    n, cam_h, cam_w = camera.shape
+    p = IngestParams(cam_w, cam_h, crop_w, crop_h)
+    if cropped is None:
+        cropped = torch.empty((n, crop_h, crop_w), dtype=torch.uint8, device=camera.device)
+    if hist is None and want_hist:
+        hist = torch.empty((n, 10), dtype=torch.int32, device=camera.device)
+    stream = torch.cuda.current_stream(camera.device).cuda_stream
+    rc = lib.aof_ingest_batch_device(C.byref(p), camera.data_ptr(), camera.stride(0), n,
+                                     cropped.data_ptr(), cropped.stride(0) if n else crop_w * crop_h,
+                                     hist.data_ptr() if hist is not None else None, stream)
+    if rc:
+        raise AofError(rc, lib.aof_strerror(rc).decode())
+    return cropped, hist
+
+
+def exposure_msv(hist) -> float:
+    h = np.ascontiguousarray(np.asarray(hist), dtype=np.uint32)
+    assert h.shape == (10,)
+    return float(lib.aof_exposure_msv(h.ctypes.data))
 
 
 class FlowEngine:

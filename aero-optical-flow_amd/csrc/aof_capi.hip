@@ -325,6 +325,23 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
     return 0;
 }
 
+int aof_ingest_batch_device(const aof_ingest_params *p, const uint8_t *d_camera,
+                            int64_t camera_stride, int64_t n_frames, uint8_t *d_cropped,
+                            int64_t cropped_stride, uint32_t *d_hist, void *stream)
+{
+    if (!p || n_frames < 0) return -EINVAL;
+    if (p->crop_width < 1 || p->crop_height < 1 || p->crop_width > p->camera_width ||
+        p->crop_height > p->camera_height)
+        return -EINVAL;
+    if (n_frames == 0) return 0;
+    if (!d_camera || (!d_cropped && !d_hist)) return -EINVAL;
+    if (camera_stride < (int64_t)p->camera_width * p->camera_height && n_frames > 1) return -EINVAL;
+    if (d_cropped && cropped_stride < (int64_t)p->crop_width * p->crop_height && n_frames > 1) return -EINVAL;
+    if (n_frames * ((p->crop_height + 15) / 16) > 0x7FFFFFFF) return -EINVAL;
+    return launch_ingest(*p, d_camera, camera_stride, n_frames, d_cropped, cropped_stride, d_hist, stream)
+               ? -EIO : 0;
+}
+
 // ---- host-buffer conveniences ------------------------------------------------
 
 static int ensure_host_state(aof_ctx *ctx)

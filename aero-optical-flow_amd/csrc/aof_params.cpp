@@ -112,6 +112,21 @@ const char *aof_strerror(int code)
     }
 }
 
+float aof_exposure_msv(const uint32_t hist[AOF_EXPOSURE_BINS])
+{
+    // /root/reference/src/mainloop.cpp:216-220, same float operation order
+    float msv = 0.0f;
+    for (int i = 0; i < AOF_EXPOSURE_BINS; i++) msv += (i + 1) * (float)hist[i] / 16384.0f;
+    return msv;
+}
+
+int aof_exposure_bin(int grey)
+{
+    if (grey < 0 || grey > 255) return -1;
+    const int b = (grey * 10) / 255;  // == cvFloor(grey * (10 / 255.0)) for every 8-bit value
+    return b < AOF_EXPOSURE_BINS ? b : -1;
+}
+
 int aof_params_default(aof_params *p, int width, int height)
 {
     if (!p) return -EINVAL;

@@ -147,6 +147,29 @@ int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, ao
 int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow);
 int aof_stream_reset(aof_ctx *ctx);
 
+/* ---- frame ingest: the caller-side steps the reference runs on
+ * the host right before calcFlow, moved next to the data so a full sensor frame is
+ * uploaded once: centre crop to the engine's frame size with a contiguous copy
+ * (/root/reference/src/mainloop.cpp:295-298,317-319) and the 10-bin histogram of the
+ * centred 128x128 region of the cropped image that feeds the auto-exposure loop
+ * (mainloop.cpp:203-214; EXPOSURE_MASK_SIZE :52).  Stateless. ---- */
+#define AOF_EXPOSURE_BINS 10
+#define AOF_EXPOSURE_MASK_SIZE 128
+typedef struct aof_ingest_params {
+    int32_t camera_width, camera_height; /* Y plane of the sensor frame, stride == width */
+    int32_t crop_width, crop_height;     /* engine frame size (getImageWidth/Height) */
+} aof_ingest_params;
+/* d_camera: frame i at +i*camera_stride bytes.  d_cropped: [n][crop_h][crop_w], frame i at
+ * +i*cropped_stride (pass it on to aof_flow_batch_device).  d_hist: uint32 [n][10] or NULL.
+ * Either output may be NULL.  Asynchronous on `stream`. */
+int aof_ingest_batch_device(const aof_ingest_params *p, const uint8_t *d_camera,
+                            int64_t camera_stride, int64_t n_frames, uint8_t *d_cropped,
+                            int64_t cropped_stride, uint32_t *d_hist, void *stream);
+/* Mean sample value of one histogram, exactly as mainloop.cpp:216-220 computes it. */
+float aof_exposure_msv(const uint32_t hist[AOF_EXPOSURE_BINS]);
+/* Histogram bin (0..9) of a grey value, -1 if cv::calcHist would drop it (v == 255). */
+int aof_exposure_bin(int grey);
+
 /* ---- measurement ----
  * With profiling on, every launch is bracketed by HIP events on the stream it
  * is launched on; the last AOF_PROFILE_RING launches of each kernel are kept.

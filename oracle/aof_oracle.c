@@ -424,6 +424,56 @@ int orc_flow_batch(const orc_params *p, const uint8_t *prev, const uint8_t *cur,
     return used;
 }
 
+/* ---- frame ingest (reference code present: /root/reference/src/mainloop.cpp) ---- */
+void orc_crop_rect(int cam_w, int cam_h, int crop_w, int crop_h, int *x0, int *y0)
+{
+    *x0 = cam_w / 2 - crop_w / 2; /* mainloop.cpp:295 */
+    *y0 = cam_h / 2 - crop_h / 2; /* mainloop.cpp:296 */
+}
+
+int orc_exposure_bin(int v)
+{
+    /* cv::calcHist, uniform ranges: idx = cvFloor(v * (histSize / (high - low)) - low * ...)
+     * with histSize = 10, low = 0, high = 255 (mainloop.cpp:210-214); out of range is dropped. */
+    const double a = (double)ORC_EXPOSURE_BINS / (255.0 - 0.0);
+    int idx = (int)floor((double)v * a);
+    return (idx >= 0 && idx < ORC_EXPOSURE_BINS) ? idx : -1;
+}
+
+int orc_ingest(const uint8_t *cam, int cam_w, int cam_h, int crop_w, int crop_h, uint8_t *crop_out,
+               uint32_t hist[ORC_EXPOSURE_BINS])
+{
+    if (!cam || crop_w < 1 || crop_h < 1 || crop_w > cam_w || crop_h > cam_h) return -EINVAL;
+    int x0, y0;
+    orc_crop_rect(cam_w, cam_h, crop_w, crop_h, &x0, &y0);
+    /* mask rectangle inside the cropped image, mainloop.cpp:203-206 */
+    int mx0 = crop_w / 2 - ORC_EXPOSURE_MASK_SIZE / 2, my0 = crop_h / 2 - ORC_EXPOSURE_MASK_SIZE / 2;
+    int mx1 = mx0 + ORC_EXPOSURE_MASK_SIZE, my1 = my0 + ORC_EXPOSURE_MASK_SIZE;
+    if (mx0 < 0) mx0 = 0;
+    if (my0 < 0) my0 = 0;
+    if (mx1 > crop_w) mx1 = crop_w;
+    if (my1 > crop_h) my1 = crop_h;
+    if (hist) memset(hist, 0, sizeof(uint32_t) * ORC_EXPOSURE_BINS);
+    for (int y = 0; y < crop_h; y++)
+        for (int x = 0; x < crop_w; x++) {
+            const uint8_t v = cam[(int64_t)(y0 + y) * cam_w + (x0 + x)];
+            if (crop_out) crop_out[(int64_t)y * crop_w + x] = v;
+            if (hist && x >= mx0 && x < mx1 && y >= my0 && y < my1) {
+                int b = orc_exposure_bin(v);
+                if (b >= 0) hist[b]++;
+            }
+        }
+    return 0;
+}
+
+float orc_exposure_msv(const uint32_t hist[ORC_EXPOSURE_BINS])
+{
+    float msv = 0.0f;
+    for (int i = 0; i < ORC_EXPOSURE_BINS; i++)
+        msv += (float)(i + 1) * (float)hist[i] / 16384.0f; /* mainloop.cpp:219 */
+    return msv;
+}
+
 /* ---- facade semantics ---------------------------------------------------
  * The calcFlow contract visible at /root/reference/src/mainloop.cpp:322-331:
  * keep the previous frame, return a negative value until 1/output_rate has

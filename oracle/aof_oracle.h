@@ -104,6 +104,25 @@ int orc_flow_batch(const orc_params *p, const uint8_t *prev, const uint8_t *cur,
                    int64_t pair_stride, int64_t n_pairs, orc_block *blocks,
                    orc_flow *flows, int threads);
 
+/* --- frame ingest: the caller-side steps the reference runs on the host just
+ *     before calcFlow.  Unlike the engine these ARE
+ *     present in the reference, so each function cites the lines it follows. --- */
+#define ORC_EXPOSURE_MASK_SIZE 128 /* /root/reference/src/mainloop.cpp:52 */
+#define ORC_EXPOSURE_BINS 10       /* mainloop.cpp:210 */
+/* Centre crop rectangle, mainloop.cpp:295-297. */
+void orc_crop_rect(int cam_w, int cam_h, int crop_w, int crop_h, int *x0, int *y0);
+/* Histogram bin of a grey value as cv::calcHist computes it for 10 uniform bins over
+ * the half-open range [0,255) (mainloop.cpp:208-214): floor(v * (10/255.0)) in double;
+ * returns -1 for values outside the range (v == 255). */
+int orc_exposure_bin(int v);
+/* crop (mainloop.cpp:295-298,317-319: contiguous copy) + masked histogram of the centred
+ * 128x128 region of the CROPPED image (mainloop.cpp:203-214).  The reference needs
+ * crop >= 128 (cv::Rect outside the matrix asserts); smaller crops clip the mask here. */
+int orc_ingest(const uint8_t *cam, int cam_w, int cam_h, int crop_w, int crop_h,
+               uint8_t *crop_out, uint32_t hist[ORC_EXPOSURE_BINS]);
+/* Mean sample value, mainloop.cpp:216-220: sum (i+1)*hist[i]/16384.0f in float, i ascending. */
+float orc_exposure_msv(const uint32_t hist[ORC_EXPOSURE_BINS]);
+
 /* --- facade semantics (calcFlow: previous-frame keeping, rate limiting,
  *     pixel->angle conversion), mainloop.cpp:322-331,359-363 ---------------- */
 typedef struct orc_px4 {

@@ -62,6 +62,11 @@ def _load():
     lib.orc_reduce.argtypes = [P(Params), VP, VP, C.c_int, C.c_int, VP, P(C.c_int32), P(C.c_int32)]
     lib.orc_flow_pair.argtypes = [P(Params), VP, VP, VP, VP, VP, VP, VP]
     lib.orc_flow_batch.argtypes = [P(Params), VP, VP, C.c_int64, C.c_int64, VP, VP, C.c_int]
+    lib.orc_crop_rect.argtypes = [C.c_int] * 4 + [P(C.c_int), P(C.c_int)]
+    lib.orc_exposure_bin.argtypes = [C.c_int]
+    lib.orc_ingest.argtypes = [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]
+    lib.orc_exposure_msv.restype = C.c_float
+    lib.orc_exposure_msv.argtypes = [VP]
     lib.orc_px4_init.argtypes = [P(Px4State), P(Params), C.c_float, C.c_float, C.c_int]
     lib.orc_px4_free.argtypes = [P(Px4State)]
     lib.orc_px4_calc_flow.argtypes = [P(Px4State), VP, C.c_uint32, P(C.c_int), P(C.c_float),
@@ -194,6 +199,27 @@ def reduce(p: Params, blocks, subdirs, rng):
     lib.orc_reduce(C.byref(p), blocks.ctypes.data, sd.ctypes.data if sd is not None else None,
                    blocks.size, rng, flow.ctypes.data, C.byref(px), C.byref(py))
     return flow[0], px.value, py.value
+
+
+def ingest(cam, crop_w, crop_h):
+    """(cropped frame, 10-bin exposure histogram) of one camera frame."""
+    cam = _u8(cam)
+    h, w = cam.shape
+    crop = np.zeros((crop_h, crop_w), dtype=np.uint8)
+    hist = np.zeros(10, dtype=np.uint32)
+    rc = lib.orc_ingest(cam.ctypes.data, w, h, crop_w, crop_h, crop.ctypes.data, hist.ctypes.data)
+    if rc:
+        raise ValueError(rc)
+    return crop, hist
+
+
+def exposure_msv(hist):
+    hist = np.ascontiguousarray(hist, dtype=np.uint32)
+    return float(lib.orc_exposure_msv(hist.ctypes.data))
+
+
+def exposure_bin(v):
+    return int(lib.orc_exposure_bin(int(v)))
 
 
 class Px4:
