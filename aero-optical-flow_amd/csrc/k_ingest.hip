@@ -8,9 +8,12 @@
 // HBM-bound byte mover: only the crop window of each sensor frame is read (16 B per lane,
 // rows of the window are contiguous runs of crop_w bytes) and written once.  The bin of
 // a grey value is floor(v*10/255) -- equal to cv::calcHist's double arithmetic for all
-// 256 values (tests/test_ingest.py) -- with v = 255 outside the half-open range.  Each
-// wave votes into its own 10-bin LDS histogram, merged once per workgroup with integer
-// global atomics (order-independent).
+// 256 values (tests/test_ingest.py) -- with v = 255 outside the half-open range.  A lane
+// counts the 16 pixels of its piece in two registers of packed 12-bit fields (5 bins
+// each; a whole wave's 1024 pixels still fit a field), the wave adds them with a
+// butterfly of shuffles, and one lane per wave adds the ten sums to the workgroup's LDS
+// histogram; a single integer global atomic per bin and workgroup publishes it
+// (order-independent).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 
@@ -19,21 +22,44 @@ namespace aof {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kRowsPerBlock = 16;
+constexpr int kRowsPerBlock = 32;
+constexpr int kField = 12;  // bits per packed counter
 
 __device__ __forceinline__ int exposure_bin(uint32_t v) { return (int)((v * 10u) / 255u); }  // 10 => dropped
+
+// Wave-wide sum of the packed counters (callers flush after at most 3 pieces per lane, so
+// a field holds <= 3 x 16 x 64 = 3072 < 2^12), then one lane adds the ten totals to the
+// workgroup histogram.  Must be called by every lane of the wave.
+__device__ __forceinline__ void flush_counts(uint32_t *s_hist, u64 lo, u64 hi)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo += ((u64)(uint32_t)__shfl_xor((int)(lo >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)lo, o, 64);
+        hi += ((u64)(uint32_t)__shfl_xor((int)(hi >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)hi, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+            const uint32_t c0 = (uint32_t)(lo >> (kField * b)) & ((1u << kField) - 1);
+            const uint32_t c1 = (uint32_t)(hi >> (kField * b)) & ((1u << kField) - 1);
+            if (c0) atomicAdd(&s_hist[b], c0);
+            if (c1) atomicAdd(&s_hist[b + 5], c1);
+        }
+    }
+}
 
 __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const uint8_t *camera,
                                                      int64_t camera_stride, uint8_t *cropped,
                                                      int64_t cropped_stride, uint32_t *hist, int nstrips,
                                                      int vec)
 {
-    __shared__ uint32_t s_hist[kThreads / 64][AOF_EXPOSURE_BINS + 1];
+    __shared__ uint32_t s_hist[AOF_EXPOSURE_BINS];
     const int strip = blockIdx.x % nstrips;
     const int64_t frame = blockIdx.x / nstrips;
-    const int tid = threadIdx.x, wave = tid >> 6;
-    if (tid < (kThreads / 64) * (AOF_EXPOSURE_BINS + 1)) (&s_hist[0][0])[tid] = 0;
+    const int tid = threadIdx.x;
+    if (tid < AOF_EXPOSURE_BINS) s_hist[tid] = 0;
     __syncthreads();
+    u64 cnt_lo = 0, cnt_hi = 0;  // bins 0..4 / 5..9, kField bits each
 
     const int x0 = p.camera_width / 2 - p.crop_width / 2, y0 = p.camera_height / 2 - p.crop_height / 2;
     int mx0 = p.crop_width / 2 - AOF_EXPOSURE_MASK_SIZE / 2, my0 = p.crop_height / 2 - AOF_EXPOSURE_MASK_SIZE / 2;
@@ -46,37 +72,46 @@ __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const 
 
     if (vec) {  // crop_w % 16 == 0: one 16-byte piece per lane
         const int pieces = p.crop_width / 16, items = (row_end - row_begin) * pieces;
-        for (int it = tid; it < items; it += kThreads) {
-            const int y = row_begin + it / pieces, x = (it % pieces) * 16;
-            uint4 v;
-            __builtin_memcpy(&v, src + (int64_t)y * p.camera_width + x, 16);  // window start may be unaligned
-            if (dst) *reinterpret_cast<uint4 *>(dst + (int64_t)y * p.crop_width + x) = v;
-            if (hist && y >= my0 && y < my1 && x + 16 > mx0 && x < mx1) {
+        int round = 0;
+        for (int base = 0; base < items; base += kThreads, round++) {  // uniform trip count
+            const int it = base + tid;
+            const bool active = it < items;
+            const int y = row_begin + (active ? it / pieces : 0), x = active ? (it % pieces) * 16 : 0;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (active) {
+                __builtin_memcpy(&v, src + (int64_t)y * p.camera_width + x, 16);  // window start may be unaligned
+                if (dst) *reinterpret_cast<uint4 *>(dst + (int64_t)y * p.crop_width + x) = v;
+            }
+            if (active && hist && y >= my0 && y < my1 && x + 16 > mx0 && x < mx1) {
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const bool in = x + k >= mx0 && x + k < mx1;
                     const int b = exposure_bin((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-                    if (in) atomicAdd(&s_hist[wave][b], 1u);  // bin 10 = dropped (v == 255)
+                    // b == 10 (v == 255) is outside cv::calcHist's range: shifted out of both words
+                    cnt_lo += (in && b < 5) ? 1ull << (kField * b) : 0ull;
+                    cnt_hi += (in && b >= 5 && b < 10) ? 1ull << (kField * (b - 5)) : 0ull;
                 }
             }
+            // 3 pieces x 16 pixels x 64 lanes = 3072 < 4096: flush before a field can overflow
+            if (hist && round % 3 == 2) { flush_counts(s_hist, cnt_lo, cnt_hi); cnt_lo = cnt_hi = 0; }
         }
+        if (hist) flush_counts(s_hist, cnt_lo, cnt_hi);
     } else {
         const int items = (row_end - row_begin) * p.crop_width;
         for (int it = tid; it < items; it += kThreads) {
             const int y = row_begin + it / p.crop_width, x = it % p.crop_width;
             const uint32_t v = src[(int64_t)y * p.camera_width + x];
             if (dst) dst[(int64_t)y * p.crop_width + x] = (uint8_t)v;
-            if (hist && y >= my0 && y < my1 && x >= mx0 && x < mx1) atomicAdd(&s_hist[wave][exposure_bin(v)], 1u);
+            if (hist && y >= my0 && y < my1 && x >= mx0 && x < mx1) {
+                const int b = exposure_bin(v);
+                if (b < AOF_EXPOSURE_BINS) atomicAdd(&s_hist[b], 1u);
+            }
         }
     }
     if (!hist) return;
     __syncthreads();
-    if (tid < AOF_EXPOSURE_BINS) {
-        uint32_t s = 0;
-        for (int w = 0; w < kThreads / 64; w++) s += s_hist[w][tid];
-        if (s) atomicAdd(&hist[frame * AOF_EXPOSURE_BINS + tid], s);
-    }
+    if (tid < AOF_EXPOSURE_BINS && s_hist[tid]) atomicAdd(&hist[frame * AOF_EXPOSURE_BINS + tid], s_hist[tid]);
 }
 
 }  // namespace

@@ -83,13 +83,81 @@ def host_cores():
     return n
 
 
+def bench_ingest(args, aof, device, rank, world, dist):
+    """Caller-side row of the scope table: sensor frame -> centre crop +
+    auto-exposure histogram on the device.  Step = one launch over --pairs*8 resident frames."""
+    cam_w, cam_h, crop = 640, 480, 128
+    n = args.pairs * 8
+    g = torch.Generator(device=device)
+    g.manual_seed(77 + rank)
+    cam = torch.randint(0, 256, (n, cam_h, cam_w), generator=g, device=device, dtype=torch.uint8)
+    cropped = torch.empty((n, crop, crop), dtype=torch.uint8, device=device)
+    hist = torch.empty((n, 10), dtype=torch.int32, device=device)
+    for _ in range(args.warmup):
+        aof.ingest_batch(cam, crop, crop, cropped=cropped, hist=hist)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        aof.ingest_batch(cam, crop, crop, cropped=cropped, hist=hist)
+        b.record()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # memset + kernel on torch's stream
+    alg = 2 * crop * crop + 40
+    achieved = alg * n / (k_ms * 1e-3) / 1e9
+    out = {"metric": "sensor frames/s (640x480 -> 128x128 centre crop + 10-bin exposure histogram)",
+           "value": round(world * n * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "ingest: 640x480 sensor frames, crop 128x128, mask 128x128", "frames_per_gpu": n},
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_ingest (K0)",
+                        "kernel_ms": round(k_ms, 5), "algorithmic_bytes_per_frame": alg, "frames_per_launch": n}}
+    if rank == 0:
+        from oracle import pyoracle as orc
+        hc = cam[:4].cpu().numpy()
+        ok = True
+        for i in range(4):
+            ec, eh = orc.ingest(hc[i], crop, crop)
+            ok &= bool(np.array_equal(cropped[i].cpu().numpy(), ec) and
+                       np.array_equal(hist[i].cpu().numpy().view(np.uint32), eh))
+        out["parity"] = {"oracle_frames_bit_exact": ok, "frames_checked": 4}
+        if world == 1 and args.cpu_seconds > 0:
+            m = min(n, 2048)
+            hc = cam[:m].cpu().numpy()
+            done, spent = 0, 0.0
+            while spent < min(args.cpu_seconds, 5.0):
+                t1 = time.perf_counter()
+                for i in range(m):
+                    orc.ingest(hc[i], crop, crop)
+                spent += time.perf_counter() - t1
+                done += m
+            out["cpu_baseline"] = {"value": round(done / spent, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": f"{done} frames, scalar C oracle restating mainloop.cpp:295-298,203-214, "
+                                             f"one thread, {spent:.1f} s"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = rehearsal of the N>1 "
@@ -118,6 +186,8 @@ def main():
     aof = ge.load_package()
     import importlib
     batch = importlib.import_module(ge.PKG_NAME + ".batch")
+    if args.workload == "ingest":
+        return bench_ingest(args, aof, device, rank, world, dist)
     desc, W, H, over, reach = WORKLOADS[args.workload]
     p = aof.default_params(W, H, **over)
     eng = aof.FlowEngine(p, dev_index)
