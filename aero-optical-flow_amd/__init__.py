@@ -335,6 +335,7 @@ def facade_lib():
         f.aof_facade_destroy.argtypes = [C.c_void_p]
         f.aof_facade_calc_flow.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int),
                                            C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        f.aof_facade_px4_track_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         f.aof_facade_image_width.argtypes = [C.c_void_p]
         f.aof_facade_image_height.argtypes = [C.c_void_p]
         f.aof_facade_last_error.restype = C.c_char_p
@@ -396,6 +397,18 @@ class OpticalFlowPX4(_FacadeFlow):
         self._h = facade_lib().aof_facade_px4_create(f_length_x, f_length_y, output_rate, img_width,
                                                       img_height, search_size,
                                                       flow_feature_threshold, flow_value_threshold)
+
+
+    def trackFeatures(self, img_prev, img_current, capacity=4096):
+        """Rows of (prev_x, prev_y, cur_x, cur_y, sad, accepted) per grid tile."""
+        a = np.ascontiguousarray(img_prev, dtype=np.uint8)
+        b = np.ascontiguousarray(img_current, dtype=np.uint8)
+        out = np.zeros((capacity, 6), dtype=np.float32)
+        n = facade_lib().aof_facade_px4_track_features(self._h, a.ctypes.data, b.ctypes.data,
+                                                       out.ctypes.data, capacity)
+        if n < 0:
+            raise AofError(n, self.lastError())
+        return out[:min(n, capacity)]
 
 
 class OpticalFlowOpenCV(_FacadeFlow):

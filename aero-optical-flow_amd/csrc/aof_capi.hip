@@ -32,7 +32,8 @@ struct aof_ctx {
     int64_t ev_count[AOF_K_COUNT];           // launches timed since profiling was switched on
     // host-convenience state (one pair)
     hipStream_t stream;
-    uint8_t *d_frames[2];  // ping-pong: previous / current frame
+    uint8_t *d_frames[2];  // ping-pong: previous / current frame (streaming entry point)
+    uint8_t *d_pair[2];    // scratch of the stateless two-frame entry point
     int cur_slot;          // slot holding the newest frame
     bool have_prev;
     aof_block *d_blocks;
@@ -163,6 +164,7 @@ void aof_destroy(aof_ctx *ctx)
     }
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     for (int i = 0; i < 2; i++) if (ctx->d_frames[i]) (void)hipFree(ctx->d_frames[i]);
+    for (int i = 0; i < 2; i++) if (ctx->d_pair[i]) (void)hipFree(ctx->d_pair[i]);
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
     if (ctx->d_subdirs) (void)hipFree(ctx->d_subdirs);
     if (ctx->d_flow) (void)hipFree(ctx->d_flow);
@@ -354,6 +356,7 @@ static int ensure_host_state(aof_ctx *ctx)
     aof_workspace_layout(&p, 1, &L);
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_frames[i], frame));
+    for (int i = 0; i < 2; i++) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_pair[i], frame));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_blocks, sizeof(aof_block) * (size_t)ctx->g0.blocks()));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_subdirs, (size_t)ctx->g0.blocks()));
     HIP_TRY(ctx, hipMalloc(&ctx->d_ws, L.total_bytes));
@@ -393,10 +396,10 @@ int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, ao
     int rc = ensure_host_state(ctx);
     if (rc) return rc;
     const size_t frame = (size_t)ctx->params.width * ctx->params.height;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[0], prev, frame, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[1], cur, frame, hipMemcpyHostToDevice, ctx->stream));
-    ctx->have_prev = false;  // the streaming state no longer describes a sequence
-    return run_one(ctx, ctx->d_frames[0], ctx->d_frames[1], blocks, subdirs, flow);
+    // own scratch frames: the streaming state (aof_stream_push_host) is left untouched
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pair[0], prev, frame, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pair[1], cur, frame, hipMemcpyHostToDevice, ctx->stream));
+    return run_one(ctx, ctx->d_pair[0], ctx->d_pair[1], blocks, subdirs, flow);
 }
 
 int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)

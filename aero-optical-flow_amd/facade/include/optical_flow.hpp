@@ -51,6 +51,10 @@ protected:
 	// frame or on engine failure) and the pixel flow against the previous frame.
 	int pixelFlow(const uint8_t *img, float *flow_x, float *flow_y, bool *first);
 	bool openEngine(const void *params);  // aof_params
+	// Block records of one explicit image pair (no streaming state involved).
+	int blockMatches(const uint8_t *img_prev, const uint8_t *img_current, void *blocks,
+			 uint8_t *subdirs, int capacity, int *grid /* x0,y0,step_x,step_y,nx,ny */,
+			 int *tile, int *value_threshold);
 	// pixelFlow + limitRate + pixel -> angle: the whole calcFlow() contract.
 	int integrate(const uint8_t *img, uint32_t img_time_us, int &dt_us, float &flow_x,
 		      float &flow_y);

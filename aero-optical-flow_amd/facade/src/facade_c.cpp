@@ -26,6 +26,21 @@ int aof_facade_calc_flow(void *flow, uint8_t *img, uint32_t t_us, int *dt_us, fl
 	return static_cast<OpticalFlow *>(flow)->calcFlow(img, t_us, *dt_us, *flow_x, *flow_y);
 }
 
+int aof_facade_px4_track_features(void *flow, const uint8_t *prev, const uint8_t *cur, float *out6, int capacity)
+{
+	// out6: capacity rows of {prev_x, prev_y, cur_x, cur_y, sad, accepted}
+	OpticalFlowPX4 *px4 = static_cast<OpticalFlowPX4 *>(flow);
+	TrackedFeature *tmp = new TrackedFeature[capacity > 0 ? capacity : 1];
+	int n = px4->trackFeatures(prev, cur, tmp, capacity);
+	for (int k = 0; k < n && k < capacity; k++) {
+		out6[6 * k + 0] = tmp[k].prev_x; out6[6 * k + 1] = tmp[k].prev_y;
+		out6[6 * k + 2] = tmp[k].cur_x;  out6[6 * k + 3] = tmp[k].cur_y;
+		out6[6 * k + 4] = (float)tmp[k].sad; out6[6 * k + 5] = tmp[k].accepted ? 1.0f : 0.0f;
+	}
+	delete[] tmp;
+	return n;
+}
+
 int aof_facade_image_width(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageWidth(); }
 int aof_facade_image_height(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageHeight(); }
 const char *aof_facade_last_error(void *flow) { return static_cast<OpticalFlow *>(flow)->lastError(); }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "aof.h"
 #include "flow_opencv.hpp"
@@ -99,6 +100,28 @@ int OpticalFlow::pixelFlow(const uint8_t *img, float *flow_x, float *flow_y, boo
 	return f.quality;
 }
 
+int OpticalFlow::blockMatches(const uint8_t *img_prev, const uint8_t *img_current, void *blocks,
+			      uint8_t *subdirs, int capacity, int *grid, int *tile, int *value_threshold)
+{
+	if (!_ctx || !img_prev || !img_current) return -1;
+	aof_params p;
+	aof_get_params(_ctx, &p);
+	int32_t g[6];
+	if (aof_grid(&p, 0, &g[0], &g[1], &g[2], &g[3], &g[4], &g[5])) return -1;
+	const int n = g[4] * g[5];
+	if (capacity < n) return -1;
+	aof_flow f;
+	int rc = aof_flow_pair_host(_ctx, img_prev, img_current, static_cast<aof_block *>(blocks), subdirs, &f);
+	if (rc < 0) {
+		std::snprintf(_err, sizeof(_err), "%s", aof_last_error(_ctx));
+		return -1;
+	}
+	for (int k = 0; k < 6; k++) grid[k] = g[k];
+	*tile = p.tile;
+	*value_threshold = p.value_threshold > 0xFFFF ? 0xFFFF : p.value_threshold;
+	return n;
+}
+
 int OpticalFlow::integrate(const uint8_t *img, uint32_t img_time_us, int &dt_us, float &flow_x,
 			   float &flow_y)
 {
@@ -132,6 +155,35 @@ int OpticalFlowPX4::calcFlow(uint8_t *img_current, const uint32_t &img_time_us, 
 			     float &flow_x, float &flow_y)
 {
 	return integrate(img_current, img_time_us, dt_us, flow_x, flow_y);
+}
+
+int OpticalFlowPX4::trackFeatures(const uint8_t *img_prev, const uint8_t *img_current,
+				  TrackedFeature *features, int capacity)
+{
+	static const int half_x[9] = {1, 1, 0, -1, -1, -1, 0, 1, 0};  // half-pixel direction -> x step
+	static const int half_y[9] = {0, 1, 1, 1, 0, -1, -1, -1, 0};
+	aof_params p;
+	int grid[6], tile = 0, vthr = 0;
+	std::vector<aof_block> blocks(4096);
+	std::vector<uint8_t> subdirs(4096, 8);
+	int n = blockMatches(img_prev, img_current, blocks.data(), subdirs.data(), (int)blocks.size(), grid,
+			     &tile, &vthr);
+	(void)p;
+	if (n < 0) return n;
+	for (int k = 0; k < n && k < capacity; k++) {
+		const int bx = k % grid[4], by = k / grid[4];
+		const aof_block &b = blocks[k];
+		const int sd = subdirs[k] <= 8 ? subdirs[k] : 8;
+		TrackedFeature &t = features[k];
+		t.prev_x = (float)(grid[0] + bx * grid[2]) + tile * 0.5f;
+		t.prev_y = (float)(grid[1] + by * grid[3]) + tile * 0.5f;
+		const bool searched = b.sad != AOF_SAD_SKIPPED;
+		t.accepted = searched && (int)b.sad < vthr;
+		t.sad = searched ? (int)b.sad : -1;
+		t.cur_x = t.prev_x + (searched ? (float)b.dx + 0.5f * (float)half_x[sd] : 0.0f);
+		t.cur_y = t.prev_y + (searched ? (float)b.dy + 0.5f * (float)half_y[sd] : 0.0f);
+	}
+	return n;
 }
 
 // ---- OpticalFlowOpenCV ----------------------------------------------------------

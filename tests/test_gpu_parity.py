@@ -386,3 +386,35 @@ def test_replay_harness_links_and_matches_oracle(aof, orc, synth, gpu_device, tm
             assert lines[k] == (f"{k} quality={q} integration_time_us={dt} "
                                 f"integrated_x={ax:.9g} integrated_y={ay:.9g}"), (lines[k], q, dt, ax, ay)
     assert n_pub >= 4
+
+
+def test_facade_track_features_matches_oracle(aof, orc, synth, gpu_device):
+    """OpticalFlowPX4::trackFeatures: the sparse grid's tiles as tracked features."""
+    flow = aof.OpticalFlowPX4(216.0, 216.0, 15, 64, 64)
+    po = orc.px4flow_params(64, 64)
+    g = orc.grid(po, 0)
+    hx = [1, 1, 0, -1, -1, -1, 0, 1, 0]
+    hy = [0, 1, 1, 1, 0, -1, -1, -1, 0]
+    for idx, kw in enumerate([dict(shift=(2, -1)), dict(shift=(0, 3), half=(1, 0)), dict(noise=9),
+                              dict(shift=(-3, -3), half=(-1, 1))]):
+        prev, cur, _ = synth.make_pair(64, 64, 4, 60 + idx, **kw)
+        if idx == 2:
+            prev[:32] = 80  # flat upper half: gradient gate rejects those tiles
+        feats = flow.trackFeatures(prev, cur)
+        ref = orc.flow_pair(po, prev, cur)
+        assert feats.shape == (25, 6)
+        for k in range(25):
+            b, sd = ref["blocks"][k], int(ref["subdirs"][k])
+            px, py = g.x0 + (k % g.nx) * g.step_x + 4.0, g.y0 + (k // g.nx) * g.step_y + 4.0
+            searched = b["sad"] != 0xFFFF
+            exp = [px, py, px + (b["dx"] + 0.5 * hx[sd] if searched else 0), py + (b["dy"] + 0.5 * hy[sd] if searched else 0),
+                   float(b["sad"]) if searched else -1.0, 1.0 if (searched and b["sad"] < 3000) else 0.0]
+            assert list(feats[k]) == [np.float32(v) for v in exp], (idx, k, feats[k], exp)
+    # the streaming state of calcFlow is untouched by trackFeatures
+    frames, _ = synth.make_sequence(64, 64, 3, 4, seed=3, max_step=2)
+    o = orc.Px4(po, 216.0, 216.0, 0)
+    o.calc_flow(frames[0], 0)
+    flow2 = aof.OpticalFlowPX4(216.0, 216.0, 0, 64, 64)
+    flow2.calcFlow(frames[0], 0)
+    flow2.trackFeatures(frames[2], frames[0])
+    assert flow2.calcFlow(frames[1], 13333) == o.calc_flow(frames[1], 13333)
