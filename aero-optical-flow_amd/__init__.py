@@ -50,6 +50,14 @@ class IngestParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("camera_width", "camera_height", "crop_width", "crop_height")]
 
 
+class DerotateParams(C.Structure):
+    """``aof_derotate_params`` (include/aof.h)."""
+    _fields_ = [(n, C.c_float) for n in ("focal_x", "focal_y", "max_flow", "rate_threshold")]
+
+
+GYRO_DTYPE = np.dtype([("integ_x", "<f4"), ("integ_y", "<f4"), ("integ_z", "<f4"), ("dt_s", "<f4")])
+
+
 class WsLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "sums", "l1_prev", "l1_cur", "l1_blocks", "l1_subdirs", "l1_flows",
@@ -92,6 +100,7 @@ def _load():
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
         "aof_stream_reset": (C.c_int, [VP]),
         "aof_ingest_batch_device": (C.c_int, [P(IngestParams), VP, I64, I64, VP, I64, VP, VP]),
+        "aof_derotate_batch_device": (C.c_int, [P(DerotateParams), VP, VP, I64, VP, VP]),
         "aof_exposure_msv": (C.c_float, [VP]),
         "aof_exposure_bin": (C.c_int, [C.c_int]),
         "aof_set_profiling": (C.c_int, [VP, C.c_int]),
@@ -178,6 +187,21 @@ def ingest_batch(camera, crop_w, crop_h, cropped=None, hist=None, want_hist=True
     if rc:
         raise AofError(rc, lib.aof_strerror(rc).decode())
     return cropped, hist
+
+
+def derotate_batch(flows, gyro, focal_x, focal_y, max_flow, rate_threshold):
+    """Published PX4Flow gyro compensation of a batch of flow records on the device.
+    flows: uint8 CUDA tensor [n, 16] (aof_flow records); gyro: float32 CUDA tensor [n, 4]
+    (integ_x, integ_y, integ_z, dt_s).  Returns float32 [n, 2]."""
+    import torch
+    n = flows.shape[0]
+    out = torch.empty((n, 2), dtype=torch.float32, device=flows.device)
+    p = DerotateParams(focal_x, focal_y, max_flow, rate_threshold)
+    rc = lib.aof_derotate_batch_device(C.byref(p), flows.data_ptr(), gyro.data_ptr(), n, out.data_ptr(),
+                                       torch.cuda.current_stream(flows.device).cuda_stream)
+    if rc:
+        raise AofError(rc, lib.aof_strerror(rc).decode())
+    return out
 
 
 def exposure_msv(hist) -> float:

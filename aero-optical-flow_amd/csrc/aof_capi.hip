@@ -344,6 +344,15 @@ int aof_ingest_batch_device(const aof_ingest_params *p, const uint8_t *d_camera,
                ? -EIO : 0;
 }
 
+int aof_derotate_batch_device(const aof_derotate_params *p, const aof_flow *d_flows,
+                              const aof_gyro *d_gyro, int64_t n, float *d_out, void *stream)
+{
+    if (!p || n < 0) return -EINVAL;
+    if (n == 0) return 0;
+    if (!d_flows || !d_gyro || !d_out || (n + 255) / 256 > 0x7FFFFFFF) return -EINVAL;
+    return launch_derotate(*p, d_flows, d_gyro, n, d_out, stream) ? -EIO : 0;
+}
+
 // ---- host-buffer conveniences ------------------------------------------------
 
 static int ensure_host_state(aof_ctx *ctx)

@@ -91,6 +91,8 @@ int launch_search_tile8(const SearchArgs &a, void *stream);
 bool tile16_supported(const SearchArgs &a);
 int launch_search_tile16(const SearchArgs &a, void *stream);
 int launch_reduce(const ReduceArgs &a, void *stream);
+int launch_derotate(const aof_derotate_params &p, const aof_flow *flows, const aof_gyro *gyro,
+                    int64_t n, float *out, void *stream);
 int launch_ingest(const aof_ingest_params &p, const uint8_t *camera, int64_t camera_stride,
                   int64_t n_frames, uint8_t *cropped, int64_t cropped_stride, uint32_t *hist,
                   void *stream);

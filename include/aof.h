@@ -170,6 +170,27 @@ float aof_exposure_msv(const uint32_t hist[AOF_EXPOSURE_BINS]);
 /* Histogram bin (0..9) of a grey value, -1 if cv::calcHist would drop it (v == 255). */
 int aof_exposure_bin(int grey);
 
+/* ---- gyro de-rotation: the output-side neighbour of the path.
+ * The reference integrates the gyro between flow outputs and ships it next to the flow
+ * for the autopilot to de-rotate (/root/reference/src/mainloop.cpp:383-405, axis swap
+ * :364-365: "-y gives x flow, x gives y flow").  This applies the published PX4Flow
+ * compensation to a batch of flow records on the device:
+ *   if |gy| > threshold*dt:  x' = clamp(flow_x + gy*focal_x, +-max_flow)   else x' = flow_x
+ *   if |gx| > threshold*dt:  y' = clamp(flow_y - gx*focal_y, +-max_flow)   else y' = flow_y
+ * with gx, gy the gyro angles (rad) integrated over the pair's interval dt (s). ---- */
+typedef struct aof_gyro {
+    float integ_x, integ_y, integ_z; /* rad, body rates integrated over the frame interval */
+    float dt_s;                      /* the interval */
+} aof_gyro;
+typedef struct aof_derotate_params {
+    float focal_x, focal_y;  /* px (main.cpp:60-61) */
+    float max_flow;          /* clamp: search radius + 0.5 px */
+    float rate_threshold;    /* rad/s below which an axis is left alone */
+} aof_derotate_params;
+/* d_out: float [n][2] compensated pixel flow.  Asynchronous on `stream`. */
+int aof_derotate_batch_device(const aof_derotate_params *p, const aof_flow *d_flows,
+                              const aof_gyro *d_gyro, int64_t n, float *d_out, void *stream);
+
 /* ---- measurement ----
  * With profiling on, every launch is bracketed by HIP events on the stream it
  * is launched on; the last AOF_PROFILE_RING launches of each kernel are kept.

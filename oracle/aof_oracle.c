@@ -474,6 +474,26 @@ float orc_exposure_msv(const uint32_t hist[ORC_EXPOSURE_BINS])
     return msv;
 }
 
+/* ---- gyro de-rotation ---- */
+void orc_derotate(float flow_x, float flow_y, float gx, float gy, float dt_s, float focal_x,
+                  float focal_y, float max_flow, float rate_threshold, float *out_x, float *out_y)
+{
+    volatile float lim = rate_threshold * dt_s; /* volatile: one rounding per operation */
+    float x = flow_x, y = flow_y;
+    if (fabsf(gy) > lim) {
+        volatile float pix = gy * focal_x;
+        volatile float c = flow_x + pix;
+        x = c < -max_flow ? -max_flow : (c > max_flow ? max_flow : c);
+    }
+    if (fabsf(gx) > lim) {
+        volatile float pix = gx * focal_y;
+        volatile float c = flow_y - pix;
+        y = c < -max_flow ? -max_flow : (c > max_flow ? max_flow : c);
+    }
+    *out_x = x;
+    *out_y = y;
+}
+
 /* ---- facade semantics ---------------------------------------------------
  * The calcFlow contract visible at /root/reference/src/mainloop.cpp:322-331:
  * keep the previous frame, return a negative value until 1/output_rate has

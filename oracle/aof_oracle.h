@@ -123,6 +123,13 @@ int orc_ingest(const uint8_t *cam, int cam_w, int cam_h, int crop_w, int crop_h,
 /* Mean sample value, mainloop.cpp:216-220: sum (i+1)*hist[i]/16384.0f in float, i ascending. */
 float orc_exposure_msv(const uint32_t hist[ORC_EXPOSURE_BINS]);
 
+/* --- gyro de-rotation (published PX4Flow compensation).
+ *     gx, gy: gyro angles integrated over dt as the reference accumulates them
+ *     (/root/reference/src/mainloop.cpp:393-395); "-y gives x flow, x gives y flow"
+ *     (mainloop.cpp:364-365). --- */
+void orc_derotate(float flow_x, float flow_y, float gx, float gy, float dt_s, float focal_x,
+                  float focal_y, float max_flow, float rate_threshold, float *out_x, float *out_y);
+
 /* --- facade semantics (calcFlow: previous-frame keeping, rate limiting,
  *     pixel->angle conversion), mainloop.cpp:322-331,359-363 ---------------- */
 typedef struct orc_px4 {

@@ -67,6 +67,7 @@ def _load():
     lib.orc_ingest.argtypes = [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]
     lib.orc_exposure_msv.restype = C.c_float
     lib.orc_exposure_msv.argtypes = [VP]
+    lib.orc_derotate.argtypes = [C.c_float] * 9 + [P(C.c_float), P(C.c_float)]
     lib.orc_px4_init.argtypes = [P(Px4State), P(Params), C.c_float, C.c_float, C.c_int]
     lib.orc_px4_free.argtypes = [P(Px4State)]
     lib.orc_px4_calc_flow.argtypes = [P(Px4State), VP, C.c_uint32, P(C.c_int), P(C.c_float),
@@ -220,6 +221,13 @@ def exposure_msv(hist):
 
 def exposure_bin(v):
     return int(lib.orc_exposure_bin(int(v)))
+
+
+def derotate(flow_x, flow_y, gx, gy, dt_s, focal_x, focal_y, max_flow, rate_threshold):
+    ox, oy = C.c_float(), C.c_float()
+    lib.orc_derotate(flow_x, flow_y, gx, gy, dt_s, focal_x, focal_y, max_flow, rate_threshold,
+                     C.byref(ox), C.byref(oy))
+    return ox.value, oy.value
 
 
 class Px4:
