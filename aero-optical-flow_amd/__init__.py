@@ -360,12 +360,27 @@ def facade_lib():
         f.aof_facade_calc_flow.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int),
                                            C.POINTER(C.c_float), C.POINTER(C.c_float)]
         f.aof_facade_px4_track_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        f.aof_facade_pack_optical_flow_rad.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_float, C.c_float,
+                                                       C.c_double, C.c_double, C.c_double, C.c_int, C.c_uint8,
+                                                       C.c_void_p]
+        f.aof_facade_mavlink_crc.restype = C.c_uint
+        f.aof_facade_mavlink_crc.argtypes = [C.c_void_p, C.c_int]
         f.aof_facade_image_width.argtypes = [C.c_void_p]
         f.aof_facade_image_height.argtypes = [C.c_void_p]
         f.aof_facade_last_error.restype = C.c_char_p
         f.aof_facade_last_error.argtypes = [C.c_void_p]
         _facade = f
     return _facade
+
+
+def pack_optical_flow_rad(offset_ts, img_time_us, dt_us, flow_x, flow_y, gyro=(0.0, 0.0, 0.0), quality=0,
+                          seq=0) -> bytes:
+    """The OPTICAL_FLOW_RAD MAVLink 2 frame the reference would send for these calcFlow
+    outputs (/root/reference/src/mainloop.cpp:359-373, src/mavlink_tcp.cpp:142-162)."""
+    buf = (C.c_uint8 * 56)()
+    n = facade_lib().aof_facade_pack_optical_flow_rad(offset_ts, img_time_us, dt_us, flow_x, flow_y, gyro[0],
+                                                      gyro[1], gyro[2], quality, seq, buf)
+    return bytes(buf[:n])
 
 
 DEFAULT_OUTPUT_RATE = 15

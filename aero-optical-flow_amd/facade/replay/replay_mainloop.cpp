@@ -10,6 +10,7 @@
 //
 //   replay_mainloop frames.raw cam_w cam_h crop_w crop_h fps [rate] [fx fy]
 #include <flow_opencv.hpp>  // the header the reference includes (mainloop.h:36)
+#include <optical_flow_rad.hpp>
 
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,7 @@ int main(int argc, char **argv)
 	std::vector<uint8_t> frame((size_t)camera_width * camera_height);
 	uint64_t camera_initial_timestamp = 0;
 	bool have_initial = false;
+	uint8_t tx_seq = 1;  // the reference sends one COMMAND_LONG first (mavlink_tcp.cpp:74-76)
 	for (int k = 0; std::fread(frame.data(), 1, frame.size(), f) == frame.size(); k++) {
 		int dt_us = 0;
 		float flow_x_ang = 0, flow_y_ang = 0;
@@ -68,8 +70,16 @@ int main(int argc, char **argv)
 			continue;
 		}
 		// what mainloop.cpp:359-371 puts on the wire
-		std::printf("%d quality=%d integration_time_us=%d integrated_x=%.9g integrated_y=%.9g\n", k,
+		std::printf("%d quality=%d integration_time_us=%d integrated_x=%.9g integrated_y=%.9g", k,
 			    flow_quality, dt_us, flow_x_ang, flow_y_ang);
+		// the frame mavlink_tcp.cpp:142-162 would send (no gyro source here: zeros)
+		OpticalFlowRad msg;
+		fillOpticalFlowRad(msg, 5000000ull, img_time_us, dt_us, flow_x_ang, flow_y_ang, 0.0, 0.0, 0.0, flow_quality);
+		uint8_t wire[OPTICAL_FLOW_RAD_MAX_FRAME];
+		const size_t n = packOpticalFlowRad(msg, tx_seq++, MAVLINK_SYSTEM_ID_DEFAULT, MAVLINK_COMPONENT_ID_CAMERA, wire);
+		std::printf(" mavlink=");
+		for (size_t b = 0; b < n; b++) std::printf("%02x", wire[b]);
+		std::printf("\n");
 	}
 	std::fclose(f);
 	delete _optical_flow;  // mainloop.cpp:456

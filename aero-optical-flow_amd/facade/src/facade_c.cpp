@@ -2,6 +2,7 @@
 // tests via ctypes) drive the real C++ classes rather than a re-implementation.
 #include "flow_opencv.hpp"
 #include "flow_px4.hpp"
+#include "optical_flow_rad.hpp"
 
 extern "C" {
 
@@ -40,6 +41,17 @@ int aof_facade_px4_track_features(void *flow, const uint8_t *prev, const uint8_t
 	delete[] tmp;
 	return n;
 }
+
+int aof_facade_pack_optical_flow_rad(uint64_t offset_ts, uint64_t img_time_us, int dt_us, float fx, float fy,
+				     double gyro_x, double gyro_y, double gyro_z, int quality, uint8_t seq,
+				     uint8_t *out56)
+{
+	OpticalFlowRad m;
+	fillOpticalFlowRad(m, offset_ts, img_time_us, dt_us, fx, fy, gyro_x, gyro_y, gyro_z, quality);
+	return (int)packOpticalFlowRad(m, seq, MAVLINK_SYSTEM_ID_DEFAULT, MAVLINK_COMPONENT_ID_CAMERA, out56);
+}
+
+unsigned aof_facade_mavlink_crc(const uint8_t *data, int len) { return mavlinkCrcAccumulate(data, (size_t)len, 0xFFFF); }
 
 int aof_facade_image_width(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageWidth(); }
 int aof_facade_image_height(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageHeight(); }

@@ -383,8 +383,11 @@ def test_replay_harness_links_and_matches_oracle(aof, orc, synth, gpu_device, tm
             assert lines[k] == f"{k} skip"
         else:
             n_pub += 1
-            assert lines[k] == (f"{k} quality={q} integration_time_us={dt} "
-                                f"integrated_x={ax:.9g} integrated_y={ay:.9g}"), (lines[k], q, dt, ax, ay)
+            head, wire = lines[k].split(" mavlink=")
+            assert head == (f"{k} quality={q} integration_time_us={dt} "
+                            f"integrated_x={ax:.9g} integrated_y={ay:.9g}"), (lines[k], q, dt, ax, ay)
+            exp = aof.pack_optical_flow_rad(5000000, t, dt, ax, ay, quality=q, seq=n_pub & 0xFF)
+            assert wire == exp.hex(), "OPTICAL_FLOW_RAD frame of the published flow"
     assert n_pub >= 4
 
 
