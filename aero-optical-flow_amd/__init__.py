@@ -99,6 +99,7 @@ def _load():
         "aof_flow_pair_host": (C.c_int, [VP, VP, VP, VP, VP, VP]),
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
         "aof_stream_reset": (C.c_int, [VP]),
+        "aof_set_stream_graph": (C.c_int, [VP, C.c_int]),
         "aof_ingest_batch_device": (C.c_int, [P(IngestParams), VP, I64, I64, VP, I64, VP, VP]),
         "aof_derotate_batch_device": (C.c_int, [P(DerotateParams), VP, VP, I64, VP, VP]),
         "aof_exposure_msv": (C.c_float, [VP]),
@@ -323,6 +324,13 @@ class FlowEngine:
         flow = np.zeros(1, dtype=FLOW_DTYPE)
         rc = self._check(lib.aof_stream_push_host(self._ctx, frame.ctypes.data, flow.ctypes.data))
         return None if rc == 1 else flow[0]
+
+    def set_stream_graph(self, on=True):
+        """Streaming entry point: replay a captured hipGraph per frame (default) or launch eagerly."""
+        self._check(lib.aof_set_stream_graph(self._ctx, int(on)))
+
+    def stream_graph_active(self) -> bool:
+        return lib.aof_set_stream_graph(self._ctx, -1) == 1
 
     def stream_reset(self):
         self._check(lib.aof_stream_reset(self._ctx))

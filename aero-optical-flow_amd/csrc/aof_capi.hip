@@ -41,6 +41,13 @@ struct aof_ctx {
     aof_flow *d_flow;
     void *d_ws;
     size_t ws_bytes;
+    // streaming entry point as two captured hipGraphs (one per ping-pong slot):
+    // H2D of the pinned frame -> kernels -> D2H of the 16-byte result, one launch per call
+    uint8_t *h_frame;           // pinned staging copy of the caller's frame
+    aof_flow *h_flow;           // pinned result
+    hipGraphExec_t push_graph[2];
+    bool graph_disabled;        // capture failed once: stay on the plain path
+    bool capturing;
 };
 
 namespace {
@@ -67,13 +74,13 @@ struct Timed {
     aof_ctx *ctx; int id; hipStream_t s; int slot;
     Timed(aof_ctx *c, int k, hipStream_t st) : ctx(c), id(k), s(st), slot(0)
     {
-        if (!ctx->profiling) return;
+        if (!ctx->profiling || ctx->capturing) return;
         slot = (int)(ctx->ev_count[id] % AOF_PROFILE_RING);
         (void)hipEventRecord(ctx->ev[id][slot][0], s);
     }
     ~Timed()
     {
-        if (!ctx->profiling) return;
+        if (!ctx->profiling || ctx->capturing) return;
         (void)hipEventRecord(ctx->ev[id][slot][1], s);
         ctx->ev_count[id]++;
     }
@@ -162,7 +169,11 @@ void aof_destroy(aof_ctx *ctx)
                     if (ctx->ev[k][r][e]) (void)hipEventDestroy(ctx->ev[k][r][e]);
         delete[] ctx->ev;
     }
-    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; i++) if (ctx->push_graph[i]) (void)hipGraphExecDestroy(ctx->push_graph[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->h_frame) (void)hipHostFree(ctx->h_frame);
+    if (ctx->h_flow) (void)hipHostFree(ctx->h_flow);
     for (int i = 0; i < 2; i++) if (ctx->d_frames[i]) (void)hipFree(ctx->d_frames[i]);
     for (int i = 0; i < 2; i++) if (ctx->d_pair[i]) (void)hipFree(ctx->d_pair[i]);
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
@@ -371,7 +382,40 @@ static int ensure_host_state(aof_ctx *ctx)
     HIP_TRY(ctx, hipMalloc(&ctx->d_ws, L.total_bytes));
     ctx->ws_bytes = L.total_bytes;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_flow, sizeof(aof_flow)));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_frame, frame, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_flow, sizeof(aof_flow), hipHostMallocMapped | hipHostMallocCoherent));
     return 0;
+}
+
+// Captures [H2D frame -> kernels (result written to pinned host memory)] for destination
+// slot `slot` into a graph.
+// Any failure leaves the context on the plain (un-captured) path; never an error.
+static void build_push_graph(aof_ctx *ctx, int slot)
+{
+    const aof_params &p = ctx->params;
+    const size_t bytes = (size_t)p.width * p.height;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        ctx->graph_disabled = true;
+        return;
+    }
+    ctx->capturing = true;
+    bool ok = hipMemcpyAsync(ctx->d_frames[slot], ctx->h_frame, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    // K3 writes the 16-byte result straight into the pinned (device-visible, coherent) host
+    // record: no D2H copy node; it is visible to the host once the stream has drained.
+    ok = ok && aof_flow_batch_device(ctx, ctx->d_frames[1 - slot], ctx->d_frames[slot], (int64_t)bytes, 1,
+                                     ctx->d_blocks, ctx->d_subdirs, ctx->h_flow, ctx->d_ws, ctx->ws_bytes,
+                                     ctx->stream) == 0;
+    ctx->capturing = false;
+    const bool ended = hipStreamEndCapture(ctx->stream, &graph) == hipSuccess && graph;
+    if (ok && ended && hipGraphInstantiate(&ctx->push_graph[slot], graph, nullptr, nullptr, 0) == hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    ctx->push_graph[slot] = nullptr;
+    ctx->graph_disabled = true;
+    (void)hipGetLastError();
 }
 
 static int run_one(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_cur, aof_block *blocks,
@@ -411,6 +455,8 @@ int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, ao
     return run_one(ctx, ctx->d_pair[0], ctx->d_pair[1], blocks, subdirs, flow);
 }
 
+static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow, int slot);
+
 int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
 {
     if (!ctx) return -EINVAL;
@@ -419,6 +465,10 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
     if (rc) return rc;
     const size_t bytes = (size_t)ctx->params.width * ctx->params.height;
     const int slot = ctx->have_prev ? 1 - ctx->cur_slot : 0;
+    if (ctx->have_prev && !ctx->graph_disabled && !ctx->profiling) {
+        if (!ctx->push_graph[slot]) build_push_graph(ctx, slot);
+        if (ctx->push_graph[slot]) return stream_push_graph(ctx, frame, flow, slot);
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[slot], frame, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->have_prev) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may free `frame` on return
@@ -430,6 +480,25 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
     rc = run_one(ctx, ctx->d_frames[ctx->cur_slot], ctx->d_frames[slot], nullptr, nullptr, flow);
     ctx->cur_slot = slot;
     return rc;
+}
+
+// Same contract as the plain path above, one hipGraphLaunch per frame.
+static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow, int slot)
+{
+    std::memcpy(ctx->h_frame, frame, (size_t)ctx->params.width * ctx->params.height);
+    HIP_TRY(ctx, hipGraphLaunch(ctx->push_graph[slot], ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *flow = *ctx->h_flow;
+    ctx->cur_slot = slot;
+    return 0;
+}
+
+int aof_set_stream_graph(aof_ctx *ctx, int on)
+{
+    if (!ctx) return -EINVAL;
+    if (on < 0) return (ctx->push_graph[0] || ctx->push_graph[1]) ? 1 : 0;
+    ctx->graph_disabled = on == 0;
+    return 0;
 }
 
 int aof_stream_reset(aof_ctx *ctx)

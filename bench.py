@@ -83,6 +83,52 @@ def host_cores():
     return n
 
 
+def bench_c1(args, aof, rank, world, dist):
+    """configs[0]: the reference's own call shape -- ONE 64x64 frame per calcFlow() call from
+    a host buffer through the C++ facade (PX4Flow sparse grid, half-pixel refinement).
+    Latency-bound and PCIe-inclusive by construction: every call copies the frame in, runs
+    two kernels and copies 16 bytes back.  Step = --pairs consecutive calls."""
+    import importlib
+    synth = importlib.import_module(ge.PKG_NAME + ".synth")
+    frames, _ = synth.make_sequence(64, 64, 64, 4, seed=1, max_step=3)
+    flow = aof.OpticalFlowPX4(216.6677, 216.2457, 15, 64, 64)
+    calls = args.pairs
+    t_us = [0]
+
+    def step():
+        for k in range(calls):
+            flow.calcFlow(frames[k & 63], t_us[0])
+            t_us[0] = (t_us[0] + 13333) & 0xFFFFFFFF
+
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    out = {"metric": "frames/s through calcFlow() (64x64, 8x8 SAD, +-4 search, one host frame per call)",
+           "value": round(calls * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "C1 64x64 frames, PX4Flow 5x5 sparse grid, facade OpticalFlowPX4::calcFlow, "
+                                  "host buffers (PCIe-inclusive)", "calls_per_step": calls,
+                      "us_per_call": round(elapsed / (args.steps * calls) * 1e6, 2)}}
+    if rank == 0:
+        from oracle import pyoracle as orc
+        o = orc.Px4(orc.px4flow_params(64, 64), 216.6677, 216.2457, 15)
+        t1 = time.perf_counter()
+        m, t = 0, 0
+        while time.perf_counter() - t1 < min(args.cpu_seconds, 5.0):
+            o.calc_flow(frames[m & 63], t)
+            t = (t + 13333) & 0xFFFFFFFF
+            m += 1
+        spent = time.perf_counter() - t1
+        if m:
+            out["cpu_baseline"] = {"value": round(m / spent, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": f"{m} calls of the oracle's calcFlow on the same sequence, {spent:.1f} s"}
+        print(json.dumps(out), flush=True)
+
+
 def bench_ingest(args, aof, device, rank, world, dist):
     """Caller-side row of the scope table: sensor frame -> centre crop +
     auto-exposure histogram on the device.  Step = one launch over --pairs*8 resident frames."""
@@ -157,7 +203,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest"])
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = rehearsal of the N>1 "
@@ -188,6 +234,8 @@ def main():
     batch = importlib.import_module(ge.PKG_NAME + ".batch")
     if args.workload == "ingest":
         return bench_ingest(args, aof, device, rank, world, dist)
+    if args.workload == "c1":
+        return bench_c1(args, aof, rank, world, dist)
     desc, W, H, over, reach = WORKLOADS[args.workload]
     p = aof.default_params(W, H, **over)
     eng = aof.FlowEngine(p, dev_index)

@@ -146,6 +146,10 @@ int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, ao
  * the first frame after create/reset (nothing to compare, *flow zeroed), 0 afterwards. */
 int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow);
 int aof_stream_reset(aof_ctx *ctx);
+/* The streaming entry point replays a captured hipGraph (H2D frame, kernels, D2H result)
+ * per call; this switches the capture off (1 = on, the default).  Returns whether a graph
+ * is currently instantiated for the next call when on < 0 (query). */
+int aof_set_stream_graph(aof_ctx *ctx, int on);
 
 /* ---- frame ingest: the caller-side steps the reference runs on
  * the host right before calcFlow, moved next to the data so a full sensor frame is

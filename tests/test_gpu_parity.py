@@ -421,3 +421,52 @@ def test_facade_track_features_matches_oracle(aof, orc, synth, gpu_device):
     flow2.calcFlow(frames[0], 0)
     flow2.trackFeatures(frames[2], frames[0])
     assert flow2.calcFlow(frames[1], 13333) == o.calc_flow(frames[1], 13333)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(pyramid_levels=2, mean_subtract=1)])
+def test_batch_path_is_graph_capturable(aof, orc, synth, gpu_device, kw):
+    """aof_flow_batch_device only enqueues (no allocation, no sync): the whole launch
+    sequence can be captured into a hipGraph and replayed on new frame contents."""
+    import torch
+    p = aof.default_params(128, 96, **kw)
+    eng = aof.FlowEngine(p, 0)
+    n = 6
+    prev = torch.zeros((n, 96, 128), dtype=torch.uint8, device=gpu_device)
+    cur = torch.zeros_like(prev)
+    blocks = torch.zeros((n, eng.nblocks(0)), dtype=torch.int32, device=gpu_device)
+    flows = torch.zeros((n, 16), dtype=torch.uint8, device=gpu_device)
+    ws = torch.zeros(aof.workspace_layout(p, n).total_bytes, dtype=torch.uint8, device=gpu_device)
+    eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)  # warm-up outside capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+    for rep in range(2):
+        hp, hc, _ = synth.make_batch(128, 96, n, 9 if kw else 4, 3000 + 10 * rep, noise=4,
+                                     brightness=6 if kw else 0)
+        prev.copy_(torch.from_numpy(hp))
+        cur.copy_(torch.from_numpy(hc))
+        g.replay()
+        torch.cuda.synchronize()
+        check_against_oracle(aof, orc, p, hp, hc, dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows)))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(pyramid_levels=2, mean_subtract=1, grid_mode=0, subpixel=0)])
+def test_streaming_graph_and_eager_paths_agree(aof, orc, synth, gpu_device, kw):
+    """aof_stream_push_host replays a captured hipGraph per frame; switching the capture
+    off must give the same records, and both must match the oracle."""
+    p = aof.px4flow_params(64, 64, **kw) if not kw else aof.default_params(128, 96, **kw)
+    frames, _ = synth.make_sequence(p.width, p.height, 9, 4, seed=21, max_step=3)
+    po = orc.params_from(p)
+    outs = []
+    for graph in (True, False):
+        eng = aof.FlowEngine(p, 0)
+        eng.set_stream_graph(graph)
+        assert eng.stream_push(frames[0]) is None
+        got = [eng.stream_push(frames[k]).tobytes() for k in range(1, 9)]
+        assert eng.stream_graph_active() == graph
+        outs.append(got)
+        eng.close()
+    assert outs[0] == outs[1]
+    for k in range(1, 9):
+        assert outs[0][k - 1] == orc.flow_pair(po, frames[k - 1], frames[k])["flow"].tobytes()

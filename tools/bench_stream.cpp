@@ -1,0 +1,29 @@
+// Times aof_stream_push_host (the call under OpticalFlowPX4::calcFlow) with and without the
+// captured hipGraph.   g++ -O2 -Iinclude tools/bench_stream.cpp -Laero-optical-flow_amd/csrc -laof
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "aof.h"
+int main(int argc, char **argv)
+{
+    const int w = argc > 1 ? atoi(argv[1]) : 64, h = argc > 2 ? atoi(argv[2]) : 64, calls = 5000;
+    aof_params p;
+    aof_params_px4flow(&p, w, h, 4, 30, 3000);
+    std::vector<uint8_t> f[2];
+    for (int k = 0; k < 2; k++) { f[k].resize((size_t)w * h); for (auto &v : f[k]) v = rand() & 255; }
+    for (int graph = 1; graph >= 0; graph--) {
+        aof_ctx *ctx;
+        if (aof_create(&p, 0, &ctx)) { printf("no device\n"); return 1; }
+        aof_set_stream_graph(ctx, graph);
+        aof_flow out;
+        for (int i = 0; i < 50; i++) aof_stream_push_host(ctx, f[i & 1].data(), &out);
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < calls; i++) aof_stream_push_host(ctx, f[i & 1].data(), &out);
+        double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
+        printf("%dx%d graph=%d instantiated=%d: %.2f us per call (quality %d)\n", w, h, graph,
+               aof_set_stream_graph(ctx, -1), us, out.quality);
+        aof_destroy(ctx);
+    }
+    return 0;
+}
