@@ -21,7 +21,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libaof.so")
+# AOF_LIB: load another build of the same ABI (A/B timing of two kernel builds on one box)
+LIB_PATH = os.environ.get("AOF_LIB") or os.path.join(_HERE, "csrc", "libaof.so")
 
 GRID_DENSE, GRID_PX4FLOW = 0, 1
 SAD_SKIPPED = 0xFFFF

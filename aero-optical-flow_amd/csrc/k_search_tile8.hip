@@ -3,7 +3,9 @@
 //
 // Mapping.  A workgroup owns a strip of `rb` block rows of one frame pair and
 // stages the strip's pixels ONCE into LDS as two flat, fully coalesced 16-byte
-// copies (rows are contiguous in HBM because stride == width):
+// copies (rows are contiguous in HBM because stride == width), issued as LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip;
+// __syncthreads() drains it with s_waitcnt vmcnt(0) before the barrier):
 //     cur  rows [8*by0 + py, +8*rows+8)   -> smem[0 ..)
 //     prev rows [8*by0 + 4,  +8*rows)     -> smem[cur_bytes ..)
 // Each LANE then owns one whole block: it keeps the 8x8 reference tile in 16
@@ -103,8 +105,16 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         // lab: no global traffic
     } else if (!SHIFTED && delta == 0) {
         uint8_t *dst = s_cur + r_lo * W;
-        for (int o = tid * 16; o < cur_chunks * 16; o += nthreads * 16)
-            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(g_cur + o);
+        // LDS-DMA: each wave-instruction moves 1 KiB global -> LDS without touching VGPRs
+        // (destination = wave-uniform base + lane*16, so the flat copy maps 1:1)
+        const int wbase = (tid & ~63) * 16, lane16 = (tid & 63) * 16;
+        int o = wbase;
+        for (; o + 1024 <= cur_chunks * 16; o += nthreads * 16)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(g_cur + o + lane16),
+                (__attribute__((address_space(3))) void *)(dst + o), 16, 0, 0);
+        if (o < cur_chunks * 16 && o + lane16 < cur_chunks * 16)  // ragged last KiB: through VGPRs
+            *reinterpret_cast<uint4 *>(dst + o + lane16) = *reinterpret_cast<const uint4 *>(g_cur + o + lane16);
     } else {
         for (int c = tid; c < cur_chunks; c += nthreads) {
             uint4 v;  // 16-B load from a byte-aligned address (gfx950 handles unaligned global loads)
@@ -119,9 +129,16 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
             s_cur[r_lo * W + cur_chunks * 16 + tid] =
                 (uint8_t)clamp_u8((int)g_cur[cur_chunks * 16 + tid] + delta);
     }
-    if (LAB_MODE != 1)
-    for (int o = tid * 16; o < prev_chunks * 16; o += nthreads * 16)
-        *reinterpret_cast<uint4 *>(s_prev + o) = *reinterpret_cast<const uint4 *>(g_prev + o);
+    if (LAB_MODE != 1) {
+        const int wbase = (tid & ~63) * 16, lane16 = (tid & 63) * 16;
+        int o = wbase;
+        for (; o + 1024 <= prev_chunks * 16; o += nthreads * 16)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(g_prev + o + lane16),
+                (__attribute__((address_space(3))) void *)(s_prev + o), 16, 0, 0);
+        if (o < prev_chunks * 16 && o + lane16 < prev_chunks * 16)
+            *reinterpret_cast<uint4 *>(s_prev + o + lane16) = *reinterpret_cast<const uint4 *>(g_prev + o + lane16);
+    }
     if (NG > 1)
         for (int b = tid; b < rows * nx; b += nthreads) s_best[b] = 0xFFFFFFFFu;
     if (a.hist_parts)
