@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --pairs per GPU (default); strong: --pairs in total, sharded over the "
+                         "GPUs (BASELINE configs[3]: 1024 pairs over 8 GPUs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = rehearsal of the N>1 "
                          "control flow with several ranks sharing the GPUs that exist")
@@ -239,7 +242,13 @@ def main():
     desc, W, H, over, reach = WORKLOADS[args.workload]
     p = aof.default_params(W, H, **over)
     eng = aof.FlowEngine(p, dev_index)
-    n = args.pairs
+    if args.scaling == "strong":
+        sb, se = batch.shard_range(args.pairs, rank, world)
+        n = se - sb
+        if (args.pairs % world) != 0:
+            sys.exit("--scaling strong needs --pairs divisible by the number of GPUs")
+    else:
+        n = args.pairs
     prev, cur, shifts = make_batch_gpu(W, H, n, reach, 0xA0F + 7919 * rank, device,
                                        brightness=9 if p.mean_subtract else 0)
     nb = eng.nblocks(0)
@@ -321,7 +330,7 @@ def main():
         "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_gpu": n, "global_pairs": world * n,
                    "search_kernel": eng.variant, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
