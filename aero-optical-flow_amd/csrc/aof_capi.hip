@@ -268,6 +268,10 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         return fail(ctx, -ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, L.total_bytes);
     if (reinterpret_cast<uintptr_t>(d_workspace) % 256)
         return fail(ctx, -EINVAL, "workspace must be 256-byte aligned");
+    int cur_dev = -1;
+    if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev != ctx->device)
+        return fail(ctx, -EINVAL, "context was created for device %d but the calling thread's current "
+                                  "device is %d", ctx->device, cur_dev);
 
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint8_t *ws = static_cast<uint8_t *>(d_workspace);

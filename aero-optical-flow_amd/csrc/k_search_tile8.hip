@@ -300,7 +300,11 @@ int launch_search_tile8(const SearchArgs &a, void *stream)
     const int by_regs = 2048 / p.threads;  // 128 VGPRs -> 4 waves per SIMD = 16 waves per CU
     if (per_cu > by_regs) per_cu = by_regs;
     if (per_cu < 1) per_cu = 1;
-    uint32_t first_gen = 256u * (uint32_t)per_cu, stagger = 24;
+    // the spread costs up to `stagger` x ~1000 cycles once per launch: scale it down for
+    // launches of only a few generations of workgroups
+    uint32_t first_gen = 256u * (uint32_t)per_cu;
+    uint32_t stagger = (uint32_t)(4 * total / first_gen);
+    if (stagger > 24) stagger = 24;
 #ifdef AOF_LAB
     if (g_lab_stagger >= 0) stagger = (uint32_t)g_lab_stagger;
 #endif

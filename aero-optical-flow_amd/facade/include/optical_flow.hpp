@@ -51,6 +51,7 @@ protected:
 	// frame or on engine failure) and the pixel flow against the previous frame.
 	int pixelFlow(const uint8_t *img, float *flow_x, float *flow_y, bool *first);
 	bool openEngine(const void *params);  // aof_params
+	int gridTiles() const;  // tiles of the level-0 grid, -1 without an engine
 	// Block records of one explicit image pair (no streaming state involved).
 	int blockMatches(const uint8_t *img_prev, const uint8_t *img_current, void *blocks,
 			 uint8_t *subdirs, int capacity, int *grid /* x0,y0,step_x,step_y,nx,ny */,

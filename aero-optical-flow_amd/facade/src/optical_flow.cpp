@@ -122,6 +122,16 @@ int OpticalFlow::blockMatches(const uint8_t *img_prev, const uint8_t *img_curren
 	return n;
 }
 
+int OpticalFlow::gridTiles() const
+{
+	if (!_ctx) return -1;
+	aof_params p;
+	aof_get_params(_ctx, &p);
+	int32_t nx = 0, ny = 0;
+	if (aof_grid(&p, 0, NULL, NULL, NULL, NULL, &nx, &ny)) return -1;
+	return nx * ny;
+}
+
 int OpticalFlow::integrate(const uint8_t *img, uint32_t img_time_us, int &dt_us, float &flow_x,
 			   float &flow_y)
 {
@@ -162,13 +172,12 @@ int OpticalFlowPX4::trackFeatures(const uint8_t *img_prev, const uint8_t *img_cu
 {
 	static const int half_x[9] = {1, 1, 0, -1, -1, -1, 0, 1, 0};  // half-pixel direction -> x step
 	static const int half_y[9] = {0, 1, 1, 1, 0, -1, -1, -1, 0};
-	aof_params p;
 	int grid[6], tile = 0, vthr = 0;
-	std::vector<aof_block> blocks(4096);
-	std::vector<uint8_t> subdirs(4096, 8);
-	int n = blockMatches(img_prev, img_current, blocks.data(), subdirs.data(), (int)blocks.size(), grid,
-			     &tile, &vthr);
-	(void)p;
+	const int tiles = gridTiles();
+	if (tiles <= 0) return -1;
+	std::vector<aof_block> blocks((size_t)tiles);
+	std::vector<uint8_t> subdirs((size_t)tiles, 8);
+	int n = blockMatches(img_prev, img_current, blocks.data(), subdirs.data(), tiles, grid, &tile, &vthr);
 	if (n < 0) return n;
 	for (int k = 0; k < n && k < capacity; k++) {
 		const int bx = k % grid[4], by = k / grid[4];
