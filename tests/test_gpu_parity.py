@@ -470,3 +470,52 @@ def test_streaming_graph_and_eager_paths_agree(aof, orc, synth, gpu_device, kw):
     assert outs[0] == outs[1]
     for k in range(1, 9):
         assert outs[0][k - 1] == orc.flow_pair(po, frames[k - 1], frames[k])["flow"].tobytes()
+
+
+def test_c_abi_argument_handling(aof, orc, synth, gpu_device):
+    """Direct calls into the C ABI: optional outputs, error codes, many small pairs."""
+    import ctypes as C
+    import torch
+    p = aof.default_params(64, 48)
+    eng = aof.FlowEngine(p, 0)
+    n = 3000                                         # many tiny pairs in one launch
+    prevs, curs, shifts = synth.make_batch(64, 48, 8, 4, 4100)
+    tp = torch.from_numpy(np.tile(prevs, (n // 8, 1, 1))).to(gpu_device)
+    tc = torch.from_numpy(np.tile(curs, (n // 8, 1, 1))).to(gpu_device)
+    L = aof.workspace_layout(p, n)
+    ws = torch.zeros(L.total_bytes + 256, dtype=torch.uint8, device=gpu_device)
+    flows = torch.zeros((n, 16), dtype=torch.uint8, device=gpu_device)
+    stream = torch.cuda.current_stream().cuda_stream
+    call = aof.lib.aof_flow_batch_device
+    # d_blocks == NULL: records land in the workspace
+    rc = call(eng._ctx, tp.data_ptr(), tc.data_ptr(), 64 * 48, n, None, None, flows.data_ptr(),
+              ws.data_ptr(), L.total_bytes, stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    f = aof.flows_view(flows)
+    assert np.array_equal(f["flow_x"], np.tile(shifts[:, 0], n // 8).astype(np.float32))
+    nb = eng.nblocks(0)
+    rec = ws.cpu().numpy()[L.l0_blocks:L.l0_blocks + n * nb * 4].view(aof.BLOCK_DTYPE).reshape(n, nb)
+    ref = orc.flow_pair(orc.params_from(p), prevs[5], curs[5])
+    assert rec[5].tobytes() == ref["blocks"].tobytes() and rec[2997].tobytes() == ref["blocks"].tobytes()
+    # errors: misaligned workspace, missing flows, short pair stride
+    assert call(eng._ctx, tp.data_ptr(), tc.data_ptr(), 64 * 48, n, None, None, flows.data_ptr(),
+                ws.data_ptr() + 16, L.total_bytes, stream) == -22
+    assert b"aligned" in aof.lib.aof_last_error(eng._ctx)
+    assert call(eng._ctx, tp.data_ptr(), tc.data_ptr(), 64 * 48, n, None, None, None,
+                ws.data_ptr(), L.total_bytes, stream) == -22
+    assert call(eng._ctx, tp.data_ptr(), tc.data_ptr(), 100, n, None, None, flows.data_ptr(),
+                ws.data_ptr(), L.total_bytes, stream) == -22
+    assert call(eng._ctx, tp.data_ptr(), tc.data_ptr(), 64 * 48, n, None, None, flows.data_ptr(),
+                ws.data_ptr(), 1024, stream) == -28
+    assert call(None, tp.data_ptr(), tc.data_ptr(), 64 * 48, n, None, None, flows.data_ptr(),
+                ws.data_ptr(), L.total_bytes, stream) == -22
+    # profiling ring: counts launches of the timed kernels only
+    eng.set_profiling(True)
+    for _ in range(3):
+        eng.flow_batch(tp[:16], tc[:16])
+    assert len(eng.profile_ms(aof.K_SEARCH)) == 3 and len(eng.profile_ms(aof.K_PYRAMID)) == 0
+    assert all(0 < ms < 50 for ms in eng.profile_ms(aof.K_SEARCH))
+    eng.set_profiling(False)
+    par = aof.Params()
+    assert aof.lib.aof_get_params(eng._ctx, C.byref(par)) == 0 and par.width == 64 and par.search == 4
