@@ -107,14 +107,17 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         uint8_t *dst = s_cur + r_lo * W;
         // LDS-DMA: each wave-instruction moves 1 KiB global -> LDS without touching VGPRs
         // (destination = wave-uniform base + lane*16, so the flat copy maps 1:1)
-        const int wbase = (tid & ~63) * 16, lane16 = (tid & 63) * 16;
-        int o = wbase;
-        for (; o + 1024 <= cur_chunks * 16; o += nthreads * 16)
+        // address = wave-uniform base (SGPRs) + zero-extended 32-bit lane offset (one VGPR)
+        const uint32_t wbase = (uint32_t)(tid & ~63) * 16u, lane16 = (uint32_t)(tid & 63) * 16u;
+        const uint32_t total = (uint32_t)cur_chunks * 16u, step = (uint32_t)nthreads * 16u;
+        uint32_t o = wbase;
+        for (; o + 1024u <= total; o += step)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(g_cur + o + lane16),
+                (const __attribute__((address_space(1))) void *)(g_cur + (size_t)(o + lane16)),
                 (__attribute__((address_space(3))) void *)(dst + o), 16, 0, 0);
-        if (o < cur_chunks * 16 && o + lane16 < cur_chunks * 16)  // ragged last KiB: through VGPRs
-            *reinterpret_cast<uint4 *>(dst + o + lane16) = *reinterpret_cast<const uint4 *>(g_cur + o + lane16);
+        if (o < total && o + lane16 < total)  // ragged last KiB: through VGPRs
+            *reinterpret_cast<uint4 *>(dst + o + lane16) =
+                *reinterpret_cast<const uint4 *>(g_cur + (size_t)(o + lane16));
     } else {
         for (int c = tid; c < cur_chunks; c += nthreads) {
             uint4 v;  // 16-B load from a byte-aligned address (gfx950 handles unaligned global loads)
@@ -130,14 +133,16 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
                 (uint8_t)clamp_u8((int)g_cur[cur_chunks * 16 + tid] + delta);
     }
     if (LAB_MODE != 1) {
-        const int wbase = (tid & ~63) * 16, lane16 = (tid & 63) * 16;
-        int o = wbase;
-        for (; o + 1024 <= prev_chunks * 16; o += nthreads * 16)
+        const uint32_t wbase = (uint32_t)(tid & ~63) * 16u, lane16 = (uint32_t)(tid & 63) * 16u;
+        const uint32_t total = (uint32_t)prev_chunks * 16u, step = (uint32_t)nthreads * 16u;
+        uint32_t o = wbase;
+        for (; o + 1024u <= total; o += step)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(g_prev + o + lane16),
+                (const __attribute__((address_space(1))) void *)(g_prev + (size_t)(o + lane16)),
                 (__attribute__((address_space(3))) void *)(s_prev + o), 16, 0, 0);
-        if (o < prev_chunks * 16 && o + lane16 < prev_chunks * 16)
-            *reinterpret_cast<uint4 *>(s_prev + o + lane16) = *reinterpret_cast<const uint4 *>(g_prev + o + lane16);
+        if (o < total && o + lane16 < total)
+            *reinterpret_cast<uint4 *>(s_prev + o + lane16) =
+                *reinterpret_cast<const uint4 *>(g_prev + (size_t)(o + lane16));
     }
     if (NG > 1)
         for (int b = tid; b < rows * nx; b += nthreads) s_best[b] = 0xFFFFFFFFu;
