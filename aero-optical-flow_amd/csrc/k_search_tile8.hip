@@ -178,10 +178,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     if ((tid & ~63) < nblk * NG) {
     // reference tile: 8 rows x 2 dwords, frame column 8*bx + 4
     uint32_t ref[8][2];
+    // LDS offsets as 32-bit integers from the one shared array (no 64-bit pointer maths)
+    const uint32_t prev_off = (uint32_t)((8 * rb + 8) * W);
+    const uint32_t ref_off = prev_off + (uint32_t)(8 * brow * W + 8 * bx + 4);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const uint32_t *p =
-            reinterpret_cast<const uint32_t *>(s_prev + (8 * brow + r) * W + 8 * bx + 4);
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(smem + (ref_off + (uint32_t)(r * W)));
         ref[r][0] = p[0];
         ref[r][1] = p[1];
     }
@@ -208,10 +210,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
 #pragma unroll
     for (int d = 0; d < DYG; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)((s0 + d) * 9 + 8); }
 
-    const uint8_t *win = s_cur + (8 * brow + s0) * W + xs;
+    const uint32_t win_off = (uint32_t)((8 * brow + s0) * W + xs);  // s_cur is at offset 0
 #pragma unroll
     for (int s = 0; s < kRows; s++) {
-        const uint2 *p = reinterpret_cast<const uint2 *>(win + s * W);
+        const uint2 *p = reinterpret_cast<const uint2 *>(smem + (win_off + (uint32_t)(s * W)));
         const uint2 a0 = p[0], a1 = p[1];
         const uint32_t w0 = a0.x, w1 = a0.y, w2 = a1.x, w3 = a1.y;
         const u64 p01 = pack64(w0, w1), p12 = pack64(w1, w2), p23 = pack64(w2, w3);
@@ -258,7 +260,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         rec.dy = (int8_t)(py + idx / 9 - 4);
         rec.sad = (uint16_t)(best >> 16);
     }
-    if (writer) a.blocks[pair * (int64_t)(nx * ny) + (int64_t)(by0 + brow) * nx + bx] = rec;
+    // the strip's records are contiguous: (by0 + brow)*nx + bx == by0*nx + blk; keep the
+    // 64-bit part of the address wave-uniform (SALU) and the lane part 32-bit
+    aof_block *strip_out = a.blocks + (pair * (int64_t)(nx * ny) + (int64_t)by0 * nx);
+    if (writer) strip_out[(uint32_t)blk] = rec;
 
     // Votes of this strip's accepted blocks, so that K3 sums nstrips small histograms per
     // pair instead of re-reading every record (DESIGN.md "Kernels": K3).
