@@ -37,7 +37,8 @@ def main():
             lines.append(f"    => HBM read {rd/1e6:.1f} MB (FETCH_SIZE x2, gfx950 correction) + write {wr/1e6:.1f} MB per launch")
     open(out_txt, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
-    search = [k for k in traffic if k.startswith("k_search")]
+    # the level-0 search is the k_search kernel that moves the most bytes
+    search = sorted((k for k in traffic if k.startswith("k_search")), key=lambda k: -sum(traffic[k]))
     if search:
         rd, wr = traffic[search[0]]
         path = os.path.join(os.path.dirname(os.path.abspath(out_txt)), "pmc_traffic.json")
