@@ -25,6 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOF_LIB") or os.path.join(_HERE, "csrc", "libaof.so")
 
 GRID_DENSE, GRID_PX4FLOW = 0, 1
+SEARCH_EXHAUSTIVE, SEARCH_PRUNED = 0, 1
 SAD_SKIPPED = 0xFFFF
 FLAG_FLOW_VALID, FLAG_PRED_VALID = 1, 2
 K_PYRAMID, K_SEARCH_L1, K_REDUCE_L1, K_SEARCH, K_REDUCE = range(5)
@@ -96,6 +97,7 @@ def _load():
         "aof_get_params": (C.c_int, [VP, P(Params)]),
         "aof_search_variant": (C.c_char_p, [VP]),
         "aof_set_force_generic": (C.c_int, [VP, C.c_int]),
+        "aof_set_search_mode": (C.c_int, [VP, C.c_int]),
         "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
         "aof_flow_pair_host": (C.c_int, [VP, VP, VP, VP, VP, VP]),
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
@@ -243,6 +245,10 @@ class FlowEngine:
 
     def force_generic(self, on=True):
         self._check(lib.aof_set_force_generic(self._ctx, int(on)))
+
+    def set_search_mode(self, mode):
+        """SEARCH_EXHAUSTIVE (default) or SEARCH_PRUNED (exact, data-dependent rate)."""
+        self._check(lib.aof_set_search_mode(self._ctx, int(mode)))
 
     def set_profiling(self, on=True):
         self._check(lib.aof_set_profiling(self._ctx, int(on)))

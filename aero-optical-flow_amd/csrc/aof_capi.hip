@@ -26,6 +26,7 @@ struct aof_ctx {
     int device;
     bool force_generic;
     bool profiling;
+    int search_mode;
     const char *variant;
     char err[256];
     hipEvent_t (*ev)[AOF_PROFILE_RING][2];  // [AOF_K_COUNT][ring][start,stop], created on demand
@@ -102,6 +103,7 @@ SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const
     a.blocks = blocks; a.subdirs = p.subpixel ? subdirs : nullptr;
     a.pred = pred; a.sums = sums; a.level = level; a.n_pairs = n;
     a.hist_parts = nullptr; a.hist_range = level_range(p, level);
+    a.prune = ctx->search_mode == AOF_SEARCH_PRUNED;
     return a;
 }
 
@@ -202,6 +204,17 @@ int aof_set_force_generic(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
     ctx->force_generic = on != 0;
+    return 0;
+}
+
+int aof_set_search_mode(aof_ctx *ctx, int mode)
+{
+    if (!ctx || (mode != AOF_SEARCH_EXHAUSTIVE && mode != AOF_SEARCH_PRUNED)) return -EINVAL;
+    if (mode != ctx->search_mode) {  // captured graphs hold the old kernel
+        for (int i = 0; i < 2; i++)
+            if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
+    }
+    ctx->search_mode = mode;
     return 0;
 }
 

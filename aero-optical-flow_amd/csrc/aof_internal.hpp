@@ -52,6 +52,7 @@ struct SearchArgs {
     int64_t n_pairs;
     uint32_t *hist_parts;      // tile8 only: [n_pairs][nstrips][2][2*(2R+1)+1] per-strip vote histograms
     int32_t hist_range;        // R
+    int32_t prune;             // tile8 only: exact partial-distortion elimination
 };
 
 struct ReduceArgs {

@@ -36,6 +36,8 @@ constexpr int kMaxThreads = 512;
 #ifdef AOF_LAB  // experiment knobs of tools/k2_lab.hip; never defined in the product build
 int g_lab_stagger = -1;     // first-generation stagger units (-1 = product default)
 __constant__ int c_lab_mode;  // 1: skip staging loads, 2: skip the search
+__constant__ int c_lab_count;  // 1: count rows in the pruned search (slow)
+__device__ unsigned long long d_lab_rows[2];  // pruned search: rows visited / rows fully evaluated
 #define LAB_MODE c_lab_mode
 #else
 #define LAB_MODE 0
@@ -51,7 +53,15 @@ __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)h
 // lane; 3 = three lanes per block, each doing three of the nine dy rows (less state per
 // lane, smaller strips, more resident waves); the partial minima of a block then meet in
 // an LDS atomicMin on the packed key -- integer min, so still exactly first-minimum-wins.
-template <int DYG, bool SHIFTED>
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t x, uint32_t y)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, x),
+                                                                  __builtin_bit_cast(ushort2_t, y)));
+}
+
+// PRUNE = exact partial-distortion elimination (include/aof.h: AOF_SEARCH_PRUNED).
+template <int DYG, bool SHIFTED, bool PRUNE>
 __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int rb, int nstrips,
                                                               uint32_t total_wgs, uint32_t first_gen,
                                                               uint32_t stagger_units)
@@ -80,6 +90,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
 
     int px = 0, py = 0;
     if (SHIFTED) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
+
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * H));
 
     // ---- stage the strip into LDS (flat 16-byte copies) ----
@@ -204,6 +215,104 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         }
     }
 
+    if constexpr (PRUNE) {
+        static_assert(!PRUNE || DYG == 9, "the pruned search keeps one block per lane");
+        // Exact pruning.  A partial SAD only grows, so once a row's partial sums all exceed a
+        // lane's best SAD the row cannot win (nor tie) for that lane; the wave drops the row
+        // when that holds for every lane that still needs a result.  Rows are visited outwards
+        // from dy = 0 (the predictor's row in the 2-level search), so small motions meet their
+        // row early and the remaining rows cost two row pairs each.  (A per-pair hint word
+        // shared between workgroups was tried: its agent-scope load/store cost more than the
+        // better order saved, and workgroups of one pair run concurrently anyway.)
+        const bool need = live && inside && diff >= (uint32_t)a.feature_threshold;
+        constexpr int start = 4;
+        const uint32_t win_base = (uint32_t)(8 * brow * W + xs);
+        // Only the two rows of the first test (r = 0, 4) are fetched ahead, one dy row early
+        // (ping-pong registers), so pruned rows cost two LDS reads; the other six rows are read
+        // only when the row survives.  (Fetching all eight ahead made the kernel LDS-bound:
+        // 72 reads per block against 16 in the exhaustive kernel.)  Two accumulator sets (even /
+        // odd row pairs) keep consecutive v_qsad independent; they are added as packed u16.
+        uint2 head_a[2][2], head_b[2][2];
+        auto fetch = [&](uint2 (&buf)[2][2], int d) {
+            const uint32_t row_off = win_base + (uint32_t)(d * W);
+            const uint2 *p0 = reinterpret_cast<const uint2 *>(smem + row_off);
+            const uint2 *p4 = reinterpret_cast<const uint2 *>(smem + (row_off + (uint32_t)(4 * W)));
+            buf[0][0] = p0[0]; buf[0][1] = p0[1];
+            buf[1][0] = p4[0]; buf[1][1] = p4[1];
+        };
+        auto evaluate = [&](const uint2 (&head)[2][2], int d) {
+            u64 alo[2] = {0, 0}, ahi[2] = {0, 0};
+            uint32_t a8[2] = {(uint32_t)(d * 9 + 8), 0u};
+            auto row_pair = [&](int r, int set, uint2 a0, uint2 a1) {
+                const u64 p01 = pack64(a0.x, a0.y), p12 = pack64(a0.y, a1.x), p23 = pack64(a1.x, a1.y);
+                alo[set] = qsad(p01, ref[r][0], alo[set]);
+                ahi[set] = qsad(p12, ref[r][0], ahi[set]);
+                alo[set] = qsad(p12, ref[r][1], alo[set]);
+                ahi[set] = qsad(p23, ref[r][1], ahi[set]);
+                a8[set] = __builtin_amdgcn_sad_hi_u8(a1.x, ref[r][0], a8[set]);
+                a8[set] = __builtin_amdgcn_sad_hi_u8(a1.y, ref[r][1], a8[set]);
+            };
+            row_pair(0, 0, head[0][0], head[0][1]);
+            row_pair(4, 1, head[1][0], head[1][1]);
+            // partial sums of two row pairs: 16 pixels <= 4080 per field, no u16 carry when added
+            const uint32_t s0 = (uint32_t)alo[0] + (uint32_t)alo[1], s1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
+            const uint32_t s2 = (uint32_t)ahi[0] + (uint32_t)ahi[1], s3 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
+            const uint32_t m = pk_min_u16(pk_min_u16(s0, s1), pk_min_u16(s2, s3));
+            const uint32_t pmin = min(min(m & 0xFFFFu, m >> 16), (a8[0] + a8[1]) >> 16);
+#ifdef AOF_LAB
+            if (c_lab_count && (tid & 63) == 0) atomicAdd(&d_lab_rows[0], 1ull);
+#endif
+            if (__ballot(need && pmin <= (best >> 16)) == 0) return;  // nobody can still improve
+#ifdef AOF_LAB
+            if (c_lab_count && (tid & 63) == 0) atomicAdd(&d_lab_rows[1], 1ull);
+#endif
+            const uint32_t row_off = win_base + (uint32_t)(d * W);
+            uint2 rest[6][2];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const int r = i < 3 ? i + 1 : i + 2;  // 1,2,3,5,6,7
+                const uint2 *p = reinterpret_cast<const uint2 *>(smem + (row_off + (uint32_t)(r * W)));
+                rest[i][0] = p[0];
+                rest[i][1] = p[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const int r = i < 3 ? i + 1 : i + 2;
+                row_pair(r, i & 1, rest[i][0], rest[i][1]);
+            }
+            // whole-row sums: 64 pixels <= 16320 per field, still no carry between the u16 fields
+            const uint32_t l0 = (uint32_t)alo[0] + (uint32_t)alo[1], l1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
+            const uint32_t h0 = (uint32_t)ahi[0] + (uint32_t)ahi[1], h1 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
+            const uint32_t base = (uint32_t)(d * 9);
+            const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
+            const uint32_t k2 = (l1 << 16) | (base + 2), k3 = (l1 & 0xFFFF0000u) | (base + 3);
+            const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
+            const uint32_t k6 = (h1 << 16) | (base + 6), k7 = (h1 & 0xFFFF0000u) | (base + 7);
+            best = min(best, min(min(k0, k1), k2));
+            best = min(best, min(min(k3, k4), k5));
+            best = min(best, min(min(k6, k7), a8[0] + a8[1]));
+        };
+        // visiting order: start, then alternately below / above it, whichever is still in range
+        // (start, start-1, start+1, start-2, ...): the k-th row in closed form, k = 0..8
+        auto order = [](int k) -> int {
+            if (k == 0) return start;
+            const int below = start, above = 8 - start;      // rows available on either side
+            const int pairs = below < above ? below : above;  // alternating part: 2*pairs rows
+            if (k <= 2 * pairs) return (k & 1) ? start - (k + 1) / 2 : start + k / 2;
+            const int rest = k - 2 * pairs;                   // one-sided tail
+            return below > above ? start - pairs - rest : start + pairs + rest;
+        };
+        if (__ballot(need) != 0) {
+            fetch(head_a, order(0));
+            for (int k = 0; k < 9; k += 2) {
+                if (k + 1 < 9) fetch(head_b, order(k + 1));
+                evaluate(head_a, order(k));
+                if (k + 1 >= 9) break;
+                if (k + 2 < 9) fetch(head_a, order(k + 2));
+                evaluate(head_b, order(k + 1));
+            }
+        }
+    } else {
     // accumulators: per dy, offsets 0..3 / 4..7 packed u16, offset 8 as (sad<<16 | idx)
     u64 acc_lo[DYG], acc_hi[DYG];
     uint32_t acc_8[DYG];
@@ -244,6 +353,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         best = min(best, min(min(k3, k4), k5));
         best = min(best, min(min(k6, k7), acc_8[d]));
     }
+    }  // exhaustive
     }  // wave has live lanes
 
     if (NG > 1) {
@@ -298,8 +408,9 @@ int launch_search_tile8(const SearchArgs &a, void *stream)
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     hipStream_t s = static_cast<hipStream_t>(stream);
     void (*fn)(SearchArgs, int, int, uint32_t, uint32_t, uint32_t);
-    if (p.dyg == 9) fn = a.pred ? k_search_tile8<9, true> : k_search_tile8<9, false>;
-    else fn = a.pred ? k_search_tile8<3, true> : k_search_tile8<3, false>;
+    if (p.dyg == 9 && a.prune) fn = a.pred ? k_search_tile8<9, true, true> : k_search_tile8<9, false, true>;
+    else if (p.dyg == 9) fn = a.pred ? k_search_tile8<9, true, false> : k_search_tile8<9, false, false>;
+    else fn = a.pred ? k_search_tile8<3, true, false> : k_search_tile8<3, false, false>;
     if (p.lds > 64 * 1024) {  // beyond the default dynamic-LDS window
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);

@@ -1,0 +1,102 @@
+"""AOF_SEARCH_PRUNED (exact partial-distortion elimination in the tile8 kernel) must return
+the same bytes as the exhaustive search and as the oracle on every kind of input: clean
+translations (maximal pruning), noise (no pruning), periodic textures and identical frames
+(ties everywhere -- the tie-break must survive the changed visiting order), flat regions
+(whole waves without a live block), saturating equalisation, displaced windows."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run(aof, p, prevs, curs, device, mode, hint_fill=None, reps=1):
+    import torch
+    eng = aof.FlowEngine(p, 0)
+    assert eng.variant == "tile8_lds"
+    eng.set_search_mode(mode)
+    tp, tc = torch.from_numpy(prevs).to(device), torch.from_numpy(curs).to(device)
+    n = prevs.shape[0]
+    L = aof.workspace_layout(p, n)
+    ws = torch.zeros(L.total_bytes, dtype=torch.uint8, device=device)
+    if hint_fill is not None:  # the workspace may hold anything on entry
+        ws.fill_(hint_fill & 0xFF)
+    for _ in range(reps):
+        blocks, flows, _ = eng.flow_batch(tp, tc, workspace=ws)
+    torch.cuda.synchronize()
+    return aof.blocks_view(blocks), aof.flows_view(flows)
+
+
+def both_modes_match_oracle(aof, orc, p, prevs, curs, device):
+    po = orc.params_from(p)
+    refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(prevs.shape[0])]
+    for mode, hint, reps in ((aof.SEARCH_EXHAUSTIVE, None, 1), (aof.SEARCH_PRUNED, None, 1),
+                             (aof.SEARCH_PRUNED, 0, 1), (aof.SEARCH_PRUNED, 8, 2),
+                             (aof.SEARCH_PRUNED, -12345, 1), (aof.SEARCH_PRUNED, 77, 3)):
+        b, f = run(aof, p, prevs, curs, device, mode, hint, reps)
+        for i, r in enumerate(refs):
+            assert b[i].tobytes() == r["blocks"].tobytes(), (mode, hint, i)
+            assert f[i].tobytes() == r["flow"].tobytes(), (mode, hint, i)
+
+
+@pytest.mark.parametrize("noise", [0, 3, 40])
+def test_pruned_vga(aof, orc, synth, gpu_device, noise):
+    p = aof.default_params(640, 480)
+    prevs, curs, _ = synth.make_batch(640, 480, 3, 4, 8100 + noise, noise=noise)
+    both_modes_match_oracle(aof, orc, p, prevs, curs, gpu_device)
+
+
+def test_pruned_unrelated_noise_and_identical_frames(aof, orc, gpu_device):
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (3, 96, 128), dtype=np.uint8)
+    b = rng.integers(0, 256, (3, 96, 128), dtype=np.uint8)
+    b[1] = a[1]                                   # identical: SAD 0 at (0,0) only
+    a[2, :, :64] = 128                            # half flat: waves without live blocks
+    for kw in (dict(), dict(value_threshold=70000, feature_threshold=0), dict(mean_subtract=1)):
+        both_modes_match_oracle(aof, orc, aof.default_params(128, 96, **kw), a, b, gpu_device)
+
+
+def test_pruned_keeps_first_minimum_on_ties(aof, orc, gpu_device):
+    img = np.zeros((96, 128), np.uint8)
+    img[:, 0::2] = 200                            # period 2 in x
+    img2 = np.zeros((96, 128), np.uint8)
+    img2[0::2, :] = 150                           # period 2 in y: every other dy row ties at SAD 0
+    img3 = np.zeros((96, 128), np.uint8)
+    img3[0::4, 0::4] = 255                        # period 4 both ways
+    yy, xx = np.mgrid[0:96, 0:128]
+    chk = (((xx // 8 + yy // 8) % 2) * 255).astype(np.uint8)
+    prevs = np.stack([img, img2, img3, chk, chk])
+    curs = np.stack([img, img2, img3, chk, 255 - chk])
+    for kw in (dict(), dict(feature_threshold=0, value_threshold=70000)):
+        p = aof.default_params(128, 96, **kw)
+        both_modes_match_oracle(aof, orc, p, prevs, curs, gpu_device)
+        b, _ = run(aof, p, prevs, curs, gpu_device, aof.SEARCH_PRUNED, hint_fill=8)
+        ok = b[1]["sad"] != 0xFFFF
+        assert (b[1]["dy"][ok] == -4).all() and (b[1]["dx"][ok] == -4).all(), "first minimum in scan order"
+
+
+def test_pruned_two_level_with_predictor(aof, orc, synth, gpu_device):
+    p = aof.default_params(192, 160, pyramid_levels=2, mean_subtract=1)
+    for shift, bright in (((9, 8), 14), ((-9, -7), -20), ((3, -2), 0), ((8, -9), 5)):
+        prev, cur, _ = synth.make_pair(192, 160, 12, 31, shift=shift, noise=2, brightness=bright)
+        both_modes_match_oracle(aof, orc, p, prev[None], cur[None], gpu_device)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_pruned_fuzz(aof, orc, synth, gpu_device, seed):
+    rng = np.random.default_rng(400 + seed)
+    w = int(rng.integers(3, 20)) * 16
+    h = int(rng.integers(40, 200))
+    kw = dict(width=w, height=h, mean_subtract=int(rng.integers(0, 2)), hist_filter=int(rng.integers(0, 2)),
+              feature_threshold=int(rng.choice([0, 30, 200])), value_threshold=int(rng.choice([0, 500, 3000, 70000])),
+              min_valid=int(rng.choice([0, 10])))
+    if rng.random() < 0.4 and h % 2 == 0:
+        kw["pyramid_levels"] = 2
+    p = aof.default_params(**kw)
+    if aof.check_params(p) != 0:
+        pytest.skip("geometry too small")
+    reach = 9 if p.pyramid_levels == 2 else 4
+    prevs, curs, _ = synth.make_batch(w, h, 3, reach, 8800 + seed, noise=int(rng.integers(0, 30)),
+                                      brightness=int(rng.integers(-25, 26)), contrast=float(rng.choice([1.0, 2.0, 0.2])))
+    if seed % 3 == 0:
+        curs[0] = rng.integers(0, 256, curs[0].shape, dtype=np.uint8)
+    both_modes_match_oracle(aof, orc, p, prevs, curs, gpu_device)

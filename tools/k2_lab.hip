@@ -51,7 +51,7 @@ int main(int argc, char **argv)
     a.prev = d_prev; a.cur = d_cur; a.pair_stride = (int64_t)frame; a.w = W; a.h = H;
     a.tile = 8; a.search = 4; a.grid = g; a.feature_threshold = 30; a.value_threshold = 3000;
     a.subpixel = 0; a.blocks = d_blocks; a.subdirs = nullptr; a.pred = nullptr; a.sums = nullptr;
-    a.level = 0; a.n_pairs = n; a.hist_parts = nullptr; a.hist_range = 4;
+    a.level = 0; a.n_pairs = n; a.hist_parts = nullptr; a.hist_range = 4; a.prune = 0;
     const double alg = (2.0 * frame + 4.0 * g.blocks() + 16) * n;
     printf("pairs %d  blocks/pair %d\n", n, g.blocks());
     printf("%4s %8s %6s %10s %10s %10s %8s\n", "rb", "threads", "lds_KB", "full_ms", "nostage_ms", "nosearch_ms", "roof%");
@@ -70,6 +70,34 @@ int main(int argc, char **argv)
         }
         printf("stag%-3d dyg%d %4d %8d %6.1f %10.4f %10.4f %10.4f %8.2f\n", stag, dyg, rb, pl.threads, pl.lds / 1024.0, t[0], t[1], t[2],
                100.0 * alg / (t[0] * 1e-3) / 8e12);
+    }
+    // pruned search: how many dy rows get the full eight row pairs?
+    {
+        g_lab_rb = 0; g_lab_dyg = 0; g_lab_stagger = -1;
+        int mode = 0;
+        CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lab_mode), &mode, sizeof(int)));
+        for (int identical = 0; identical < 2; identical++) {
+            SearchArgs b = a; b.prune = 1;
+            if (identical & 1) b.cur = b.prev;  // every block matches itself at (0,0): row 4 first, all others prunable
+            unsigned long long z[2] = {0, 0};
+            int one = 1, zero = 0;
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_lab_rows), z, sizeof(z)));
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lab_count), &one, sizeof(int)));
+            launch_search_tile8(b, nullptr);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpyFromSymbol(z, HIP_SYMBOL(d_lab_rows), sizeof(z)));
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lab_count), &zero, sizeof(int)));
+            float tm[2];
+            for (int mode2 = 0; mode2 < 2; mode2++) {
+                CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lab_mode), &mode2, sizeof(int)));
+                tm[mode2] = time_launch(b, 9);
+            }
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lab_mode), &zero, sizeof(int)));
+            float t = tm[0];
+            printf("   (no staging: %.4f ms) ", tm[1]);
+            printf("pruned %s: %.4f ms, rows visited %llu, fully evaluated %llu (%.1f %%)\n",
+                   (identical & 1) ? "cur == prev" : "unrelated frames", t, z[0], z[1], 100.0 * z[1] / (z[0] ? z[0] : 1));
+        }
     }
     return 0;
 }
