@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t x, uint32_t y)
 
 // PRUNE = exact partial-distortion elimination (include/aof.h: AOF_SEARCH_PRUNED).
 template <int DYG, bool SHIFTED, bool PRUNE>
-__global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int rb, int nstrips,
+__global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int rb, int nstrips, int spw,
                                                               uint32_t total_wgs, uint32_t first_gen,
                                                               uint32_t stagger_units)
 {
@@ -80,9 +80,16 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
+    // A workgroup walks `spw` consecutive strips of ONE pair (spw = 1 for the exhaustive search).
+    // The pruned search uses that to carry, per wave and in a register, the dy row where the
+    // previous strip's blocks matched: under a global translation the next strip then meets
+    // its row first and prunes the other eight.
     const uint32_t logical = xcd_remap(blockIdx.x, total_wgs);
-    const int strip = (int)(logical % (uint32_t)nstrips);
-    const int64_t pair = (int64_t)(logical / (uint32_t)nstrips);
+    const int wg_per_pair = (nstrips + spw - 1) / spw;
+    const int first_strip = (int)(logical % (uint32_t)wg_per_pair) * spw;
+    const int64_t pair = (int64_t)(logical / (uint32_t)wg_per_pair);
+    int start_row = 4;                                // dy index visited first (wave-uniform)
+    for (int strip = first_strip; strip < min(nstrips, first_strip + spw); strip++) {
     const int W = a.w, H = a.h, nx = a.grid.nx, ny = a.grid.ny;
     const int by0 = strip * rb;
     const int rows = min(rb, ny - by0);
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         // shared between workgroups was tried: its agent-scope load/store cost more than the
         // better order saved, and workgroups of one pair run concurrently anyway.)
         const bool need = live && inside && diff >= (uint32_t)a.feature_threshold;
-        constexpr int start = 4;
+        const int start = __builtin_amdgcn_readfirstlane(start_row);
         const uint32_t win_base = (uint32_t)(8 * brow * W + xs);
         // Only the two rows of the first test (r = 0, 4) are fetched ahead, one dy row early
         // (ping-pong registers), so pruned rows cost two LDS reads; the other six rows are read
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         };
         // visiting order: start, then alternately below / above it, whichever is still in range
         // (start, start-1, start+1, start-2, ...): the k-th row in closed form, k = 0..8
-        auto order = [](int k) -> int {
+        auto order = [start](int k) -> int {
             if (k == 0) return start;
             const int below = start, above = 8 - start;      // rows available on either side
             const int pairs = below < above ? below : above;  // alternating part: 2*pairs rows
@@ -311,6 +318,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
                 if (k + 2 < 9) fetch(head_a, order(k + 2));
                 evaluate(head_b, order(k + 1));
             }
+            // next strip of this workgroup starts where this wave's first live block matched
+            const unsigned long long needing = __ballot(need);
+            const int src = __ffsll((long long)needing) - 1;
+            start_row = (int)((uint32_t)__shfl((int)best, src, 64) & 0xFFFFu) / 9;
         }
     } else {
     // accumulators: per dy, offsets 0..3 / 4..7 packed u16, offset 8 as (sad<<16 | idx)
@@ -385,6 +396,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         uint32_t *out = a.hist_parts + ((size_t)pair * nstrips + strip) * (size_t)(2 * bins);
         for (int k = tid; k < 2 * bins; k += nthreads) out[k] = s_hist[k];
     }
+    if (spw > 1) __syncthreads();  // LDS (tiles, votes) is rewritten by the next strip
+    }  // strips of this workgroup
 }
 
 }  // namespace
@@ -404,10 +417,14 @@ int launch_search_tile8(const SearchArgs &a, void *stream)
     if (a.n_pairs == 0) return 0;
     const Tile8Plan p = plan_tile8(a.w, a.grid.nx, a.grid.ny);
     if (p.rb == 0) return (int)hipErrorInvalidValue;
-    const int64_t total = a.n_pairs * p.nstrips;
+    // pruned search: consecutive strips per workgroup, so all but the first inherit a start row;
+    // fewer on short frames, which need the workgroups for parallelism
+    int spw = 1;
+    if (a.prune && p.dyg == 9) spw = p.nstrips >= 12 ? 4 : (p.nstrips >= 8 ? 2 : 1);
+    const int64_t total = a.n_pairs * ((p.nstrips + spw - 1) / spw);
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    void (*fn)(SearchArgs, int, int, uint32_t, uint32_t, uint32_t);
+    void (*fn)(SearchArgs, int, int, int, uint32_t, uint32_t, uint32_t);
     if (p.dyg == 9 && a.prune) fn = a.pred ? k_search_tile8<9, true, true> : k_search_tile8<9, false, true>;
     else if (p.dyg == 9) fn = a.pred ? k_search_tile8<9, true, false> : k_search_tile8<9, false, false>;
     else fn = a.pred ? k_search_tile8<3, true, false> : k_search_tile8<3, false, false>;
@@ -429,7 +446,7 @@ int launch_search_tile8(const SearchArgs &a, void *stream)
 #ifdef AOF_LAB
     if (g_lab_stagger >= 0) stagger = (uint32_t)g_lab_stagger;
 #endif
-    hipLaunchKernelGGL(fn, dim3((uint32_t)total), dim3(p.threads), p.lds, s, a, p.rb, p.nstrips,
+    hipLaunchKernelGGL(fn, dim3((uint32_t)total), dim3(p.threads), p.lds, s, a, p.rb, p.nstrips, spw,
                        (uint32_t)total, first_gen, stagger);
     return (int)hipGetLastError();
 }
