@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Long differential fuzz on a GPU box (not part of the test suite): random geometry, options
+and image statistics; exhaustive, pruned and generic device paths against the CPU oracle.
+    python tools/fuzz_gpu.py [n_cases] [first_seed]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+from oracle import pyoracle as orc  # noqa: E402
+
+aof = ge.load_package()
+synth = importlib.import_module("aero_optical_flow_amd.synth")
+
+
+def case(rng):
+    fast = rng.random() < 0.7
+    tile = 8 if fast or rng.random() < 0.5 else 16
+    search = 4 if fast else int(rng.choice([8 if tile == 16 else 4, rng.integers(1, 9)]))
+    levels = int(rng.choice([1, 1, 2]))
+    grid_mode = 0 if fast else int(rng.choice([0, 1]))
+    subpixel = 0 if fast else (1 if grid_mode else int(rng.integers(0, 2)))
+    min_dim = (tile + 2 * (search + 1) + 8) * (2 if levels == 2 else 1)
+    w = int(rng.integers(min_dim, min_dim + 400))
+    h = int(rng.integers(min_dim, min_dim + 200))
+    if fast or rng.random() < 0.5:
+        w = (w + 15) // 16 * 16
+    if levels == 2:
+        w += w & 1
+        h += h & 1
+    return dict(width=w, height=h, tile=tile, search=search, pyramid_levels=levels, grid_mode=grid_mode,
+                subpixel=subpixel, mean_subtract=int(rng.integers(0, 2)), hist_filter=int(rng.integers(0, 2)),
+                feature_threshold=int(rng.choice([0, 30, 30, 200, 2000])),
+                value_threshold=int(rng.choice([0, 500, 3000, 3000, 70000])) * (4 if tile == 16 else 1),
+                min_valid=int(rng.choice([0, 10, 10, 500])), num_blocks=int(rng.integers(2, 9)))
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    dev = torch.device("cuda:0")
+    t0, done, skipped, variants = time.time(), 0, 0, {}
+    for s in range(seed0, seed0 + n_cases):
+        rng = np.random.default_rng(50000 + s)
+        kw = case(rng)
+        p = aof.default_params(**kw)
+        if aof.check_params(p) != 0:
+            skipped += 1
+            continue
+        reach = 2 * p.search + 1 if p.pyramid_levels == 2 else p.search
+        n = 2
+        prevs, curs, _ = synth.make_batch(p.width, p.height, n, reach, 90000 + 3 * s, noise=int(rng.choice([0, 0, 3, 25])),
+                                          brightness=int(rng.integers(-40, 41)), contrast=float(rng.choice([1.0, 1.0, 3.0, 0.15])))
+        style = int(rng.integers(0, 6))
+        if style == 1:
+            curs[0] = rng.integers(0, 256, curs[0].shape, dtype=np.uint8)
+        elif style == 2:
+            prevs[1][:, : p.width // 2] = int(rng.integers(0, 256))
+        elif style == 3:
+            curs[1] = prevs[1]
+        elif style == 4:
+            period = int(rng.choice([2, 3, 4, 8]))
+            yy, xx = np.mgrid[0:p.height, 0:p.width]
+            prevs[0] = (((xx // period + yy // period) % 2) * int(rng.integers(1, 256))).astype(np.uint8)
+            curs[0] = prevs[0] if rng.random() < 0.5 else 255 - prevs[0]
+        po = orc.params_from(p)
+        refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
+        tp, tc = torch.from_numpy(prevs).to(dev), torch.from_numpy(curs).to(dev)
+        for mode in ("exhaustive", "pruned", "generic"):
+            eng = aof.FlowEngine(p, 0)
+            if mode == "generic":
+                eng.force_generic(True)
+            elif mode == "pruned":
+                eng.set_search_mode(aof.SEARCH_PRUNED)
+            nb = eng.nblocks(0)
+            sub = torch.full((n, nb), 99, dtype=torch.uint8, device=dev) if p.subpixel else None
+            blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+            torch.cuda.synchronize()
+            gb, gf = aof.blocks_view(blocks), aof.flows_view(flows)
+            for i in range(n):
+                ok = gb[i].tobytes() == refs[i]["blocks"].tobytes() and gf[i].tobytes() == refs[i]["flow"].tobytes()
+                if ok and sub is not None:
+                    ok = bool(np.array_equal(sub[i].cpu().numpy(), refs[i]["subdirs"]))
+                if not ok:
+                    print(f"MISMATCH seed {s} mode {mode} ({eng.variant}) pair {i} style {style}: {kw}", flush=True)
+                    sys.exit(1)
+            variants[eng.variant] = variants.get(eng.variant, 0) + 1
+            eng.close()
+        done += 1
+        if done % 25 == 0:
+            print(f"{done} cases ok ({time.time() - t0:.0f} s), skipped {skipped}, kernels {variants}", flush=True)
+    print(f"fuzz passed: {done} cases x 3 device paths, {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
