@@ -228,7 +228,7 @@ class FlowEngine:
         self._ws = None
 
     def close(self):
-        if getattr(self, "_ctx", None):
+        if getattr(self, "_ctx", None) and lib is not None:  # lib is None at interpreter shutdown
             lib.aof_destroy(self._ctx)
             self._ctx = None
 
