@@ -6,8 +6,12 @@
 // the (B+2S+2m)^2 search window in LDS, then every lane owns candidates
 // idx = lane, lane+64, ... of the (2S+1)^2 scan; the winner is the wave-wide
 // minimum of the packed key (sad << 16 | idx), which reproduces "first minimum
-// in scan order wins" exactly.  This kernel favours generality; the dense
-// 8x8/+-4 configuration the metric is quoted on runs k_search_tile8 instead.
+// in scan order wins" exactly.  A candidate row is read as aligned LDS dwords,
+// realigned with v_alignbyte_b32 by the lane's own byte phase and summed with
+// v_sad_u8 (4 pixels per instruction).  The half-pixel refinement spreads its
+// 8 directions x B rows over the wave and adds the rows with three shuffles.
+// This kernel favours generality; the dense 8x8/+-4 configuration the metric is
+// quoted on runs k_search_tile8 instead.
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 
@@ -17,11 +21,12 @@ namespace {
 
 constexpr int kMaxTile = 16, kMaxSearch = 8;
 constexpr int kMaxWin = kMaxTile + 2 * kMaxSearch + 2;  // with the half-pixel margin
+constexpr int kMaxPitch = (kMaxWin + 3) / 4 * 4;          // window rows start on a dword
 
 __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
 {
-    __shared__ uint8_t s_ref[kMaxTile * kMaxTile];
-    __shared__ uint8_t s_win[kMaxWin * kMaxWin];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ref[kMaxTile * kMaxTile];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[kMaxPitch * kMaxWin + 16];  // + dword over-read
 
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
@@ -42,6 +47,7 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
     // Window of the search (plus the half-pixel ring) must lie inside the frame.
     const int wx0 = i + px - S - m, wy0 = j + py - S - m;
     const int win = B + 2 * S + 2 * m;
+    const int pitch = (win + 3) & ~3;             // LDS row pitch of the window
     const bool inside = wx0 >= 0 && wy0 >= 0 && wx0 + win <= a.w && wy0 + win <= a.h;
     if (!inside) {  // wave-uniform
         if (lane == 0) { *out = rec; if (out_sd) *out_sd = 8; }
@@ -53,8 +59,9 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
     for (int t = lane; t < B * B; t += 64)
         s_ref[t] = prev[(int64_t)(j + t / B) * a.w + i + t % B];
     for (int t = lane; t < win * win; t += 64) {
-        const int v = cur[(int64_t)(wy0 + t / win) * a.w + wx0 + t % win];
-        s_win[t] = (uint8_t)clamp_u8(v + delta);
+        const int y = t / win, x = t - y * win;
+        const int v = cur[(int64_t)(wy0 + y) * a.w + wx0 + x];
+        s_win[y * pitch + x] = (uint8_t)clamp_u8(v + delta);
     }
     __syncthreads();
 
@@ -82,9 +89,17 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
     for (int idx = lane; idx < ncand; idx += 64) {
         const int cy = idx / side + m, cx = idx % side + m;  // window coords of the candidate
         uint32_t sad = 0;
-        for (int r = 0; r < B; r++)
-            for (int c = 0; c < B; c++)
-                sad += (uint32_t)abs((int)s_ref[r * B + c] - (int)s_win[(cy + r) * win + cx + c]);
+        const int shift = cx & 3;                 // this candidate's byte phase (rows share it)
+        for (int r = 0; r < B; r++) {
+            const uint32_t *wrow = reinterpret_cast<const uint32_t *>(s_win + (cy + r) * pitch + (cx & ~3));
+            const uint32_t *rrow = reinterpret_cast<const uint32_t *>(s_ref + r * B);
+            uint32_t lo = wrow[0];
+            for (int q = 0; q < B / 4; q++) {
+                const uint32_t hi = wrow[q + 1];
+                sad = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, (uint32_t)shift), rrow[q], sad);
+                lo = hi;
+            }
+        }
         const uint32_t key = (sad << 16) | (uint32_t)idx;
         best = key < best ? key : best;
     }
@@ -96,35 +111,38 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
     rec.dy = (int8_t)(py + sumy);
     rec.sad = (uint16_t)dist;
 
-    // Half-pixel refinement of accepted blocks: lane k (< 8) evaluates direction k.
+    // Half-pixel refinement of accepted blocks.
     int subdir = 8;
     if (a.subpixel && dist < (uint32_t)a.value_threshold) {
-        uint32_t acc = 0xFFFFFFFFu;
-        if (lane < 8) {
-            acc = 0;
-            const int ox = sumx + S + m, oy = sumy + S + m;  // best match, window coords
-            for (int r = 0; r < B; r++)
-                for (int c = 0; c < B; c++) {
-                    const uint8_t *q = &s_win[(oy + r) * win + ox + c];
-                    const int p00 = q[0];
-                    int v;
-                    switch (lane) {
-                    case 0: v = (p00 + q[1]) >> 1; break;
-                    case 2: v = (p00 + q[win]) >> 1; break;
-                    case 4: v = (p00 + q[-1]) >> 1; break;
-                    case 6: v = (p00 + q[-win]) >> 1; break;
-                    case 1: v = (((p00 + q[1]) >> 1) + ((q[win] + q[win + 1]) >> 1)) >> 1; break;
-                    case 3: v = (((q[win] + q[win - 1]) >> 1) + ((p00 + q[-1]) >> 1)) >> 1; break;
-                    case 5: v = (((p00 + q[-1]) >> 1) + ((q[-win] + q[-win - 1]) >> 1)) >> 1; break;
-                    default: v = (((q[-win] + q[-win + 1]) >> 1) + ((p00 + q[1]) >> 1)) >> 1; break;
-                    }
-                    acc += (uint32_t)abs((int)s_ref[r * B + c] - v);
+        // lane -> (direction k = lane & 7, row group lane >> 3): each lane sums its rows of its
+        // direction, then the eight row groups of a direction are added by xor-shuffles 8/16/32
+        const int k = lane & 7;
+        const int ox = sumx + S + m, oy = sumy + S + m;  // best match, window coords
+        uint32_t acc = 0;
+        for (int r = lane >> 3; r < B; r += 8)
+            for (int c = 0; c < B; c++) {
+                const uint8_t *q = &s_win[(oy + r) * pitch + ox + c];
+                const int p00 = q[0];
+                int v;
+                switch (k) {
+                case 0: v = (p00 + q[1]) >> 1; break;
+                case 2: v = (p00 + q[pitch]) >> 1; break;
+                case 4: v = (p00 + q[-1]) >> 1; break;
+                case 6: v = (p00 + q[-pitch]) >> 1; break;
+                case 1: v = (((p00 + q[1]) >> 1) + ((q[pitch] + q[pitch + 1]) >> 1)) >> 1; break;
+                case 3: v = (((q[pitch] + q[pitch - 1]) >> 1) + ((p00 + q[-1]) >> 1)) >> 1; break;
+                case 5: v = (((p00 + q[-1]) >> 1) + ((q[-pitch] + q[-pitch - 1]) >> 1)) >> 1; break;
+                default: v = (((q[-pitch] + q[-pitch + 1]) >> 1) + ((p00 + q[1]) >> 1)) >> 1; break;
                 }
-        }
+                acc += (uint32_t)abs((int)s_ref[r * B + c] - v);
+            }
+        acc += (uint32_t)__shfl_xor((int)acc, 8, 64);
+        acc += (uint32_t)__shfl_xor((int)acc, 16, 64);
+        acc += (uint32_t)__shfl_xor((int)acc, 32, 64);
         uint32_t mind = dist;
-        for (int k = 0; k < 8; k++) {
-            const uint32_t v = (uint32_t)__shfl((int)acc, k, 64);
-            if (v < mind) { mind = v; subdir = k; }
+        for (int dir = 0; dir < 8; dir++) {
+            const uint32_t v = (uint32_t)__shfl((int)acc, dir, 64);
+            if (v < mind) { mind = v; subdir = dir; }
         }
     }
     if (lane == 0) {

@@ -211,6 +211,7 @@ def main():
                          "the images (fast on these clean synthetic translations)")
     ap.add_argument("--max-shift", type=int, default=None,
                     help="largest synthetic shift per axis (default: the workload's search reach)")
+    ap.add_argument("--force-generic", action="store_true", help="time the generic wave-per-block kernel")
     ap.add_argument("--noise", type=int, default=0, help="+-LSB uniform noise added to the current frames")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --pairs per GPU (default); strong: --pairs in total, sharded over the "
@@ -253,6 +254,8 @@ def main():
     eng = aof.FlowEngine(p, dev_index)
     if args.search == "pruned":
         eng.set_search_mode(aof.SEARCH_PRUNED)
+    if args.force_generic:
+        eng.force_generic(True)
     if args.scaling == "strong":
         sb, se = batch.shard_range(args.pairs, rank, world)
         n = se - sb
