@@ -519,3 +519,32 @@ def test_c_abi_argument_handling(aof, orc, synth, gpu_device):
     eng.set_profiling(False)
     par = aof.Params()
     assert aof.lib.aof_get_params(eng._ctx, C.byref(par)) == 0 and par.width == 64 and par.search == 4
+
+
+def test_maximum_frame_size_and_sum_range(aof, orc, gpu_device):
+    """Largest frame the ABI accepts (2^24 pixels): the u32 pixel sums of K1 peak at
+    255 * 2^24 < 2^32, and the block grid has 261 121 tiles."""
+    import torch
+    w = h = 4096
+    assert aof.check_params(aof.default_params(w, h)) == 0
+    assert aof.check_params(aof.default_params(w, h + 2)) != 0
+    p = aof.default_params(w, h, pyramid_levels=2, mean_subtract=1)
+    rng = np.random.default_rng(1)
+    prev = np.full((h, w), 255, np.uint8)
+    cur = np.full((h, w), 254, np.uint8)
+    # one textured patch so that some blocks are searched, shifted by (3, -2)
+    patch = rng.integers(0, 256, (200, 300), dtype=np.uint8)
+    prev[1000:1200, 2000:2300] = patch
+    cur[998:1198, 2003:2303] = np.clip(patch.astype(np.int32) - 1, 0, 255).astype(np.uint8)
+    tp, tc = torch.from_numpy(prev[None]).to(gpu_device), torch.from_numpy(cur[None]).to(gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    blocks, flows, ws = eng.flow_batch(tp, tc)
+    torch.cuda.synchronize()
+    L = aof.workspace_layout(p, 1)
+    sums = ws.cpu().numpy()[L.sums:L.sums + 16].view(np.uint32).reshape(2, 2)
+    assert sums[0, 0] == prev.sum(dtype=np.uint64) and sums[1, 0] == cur.sum(dtype=np.uint64)
+    assert sums[0, 0] > 0xFE000000, "the test must sit at the top of the u32 range"
+    ref = orc.flow_pair(orc.params_from(p), prev, cur)
+    gb, gf = aof.blocks_view(blocks)[0], aof.flows_view(flows)[0]
+    assert gb.tobytes() == ref["blocks"].tobytes() and gf.tobytes() == ref["flow"].tobytes()
+    assert gf["flow_x"] == 3 and gf["flow_y"] == -2 and gf["count"] > 100
