@@ -89,6 +89,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     const int first_strip = (int)(logical % (uint32_t)wg_per_pair) * spw;
     const int64_t pair = (int64_t)(logical / (uint32_t)wg_per_pair);
     int start_row = 4;                                // dy index visited first (wave-uniform)
+    int prune_pays = 1;                               // previous strip of this wave dropped rows
     for (int strip = first_strip; strip < min(nstrips, first_strip + spw); strip++) {
     const int W = a.w, H = a.h, nx = a.grid.nx, ny = a.grid.ny;
     const int by0 = strip * rb;
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         }
     }
 
+    bool exhaustive = !PRUNE;  // pruned mode may still choose it per wave and strip (below)
     if constexpr (PRUNE) {
         static_assert(!PRUNE || DYG == 9, "the pruned search keeps one block per lane");
         // Exact pruning.  A partial SAD only grows, so once a row's partial sums all exceed a
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         // 72 reads per block against 16 in the exhaustive kernel.)  Two accumulator sets (even /
         // odd row pairs) keep consecutive v_qsad independent; they are added as packed u16.
         uint2 head_a[2][2], head_b[2][2];
+        int rows_dropped = 0;
         auto fetch = [&](uint2 (&buf)[2][2], int d) {
             const uint32_t row_off = win_base + (uint32_t)(d * W);
             const uint2 *p0 = reinterpret_cast<const uint2 *>(smem + row_off);
@@ -269,24 +272,33 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
 #ifdef AOF_LAB
             if (c_lab_count && (tid & 63) == 0) atomicAdd(&d_lab_rows[0], 1ull);
 #endif
-            if (__ballot(need && pmin <= (best >> 16)) == 0) return;  // nobody can still improve
+            if (__ballot(need && pmin <= (best >> 16)) == 0) { rows_dropped++; return; }  // nobody can improve
 #ifdef AOF_LAB
             if (c_lab_count && (tid & 63) == 0) atomicAdd(&d_lab_rows[1], 1ull);
 #endif
             const uint32_t row_off = win_base + (uint32_t)(d * W);
+            // the other six rows are requested together (one LDS round trip) ...
             uint2 rest[6][2];
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                const int r = i < 3 ? i + 1 : i + 2;  // 1,2,3,5,6,7
+                const int r = i < 2 ? 2 + 4 * i : 2 * (i - 2) + 1;  // 2, 6, then 1, 3, 5, 7
                 const uint2 *p = reinterpret_cast<const uint2 *>(smem + (row_off + (uint32_t)(r * W)));
                 rest[i][0] = p[0];
                 rest[i][1] = p[1];
             }
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                const int r = i < 3 ? i + 1 : i + 2;
-                row_pair(r, i & 1, rest[i][0], rest[i][1]);
+            // ... and a second, tighter test follows on half of the tile (row pairs 0, 2, 4, 6):
+            // under moderate noise 16 pixels are too few to separate the candidates, 32 usually are
+            row_pair(2, 0, rest[0][0], rest[0][1]);
+            row_pair(6, 1, rest[1][0], rest[1][1]);
+            {
+                const uint32_t t0 = (uint32_t)alo[0] + (uint32_t)alo[1], t1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
+                const uint32_t t2 = (uint32_t)ahi[0] + (uint32_t)ahi[1], t3 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
+                const uint32_t mm = pk_min_u16(pk_min_u16(t0, t1), pk_min_u16(t2, t3));
+                const uint32_t pmin2 = min(min(mm & 0xFFFFu, mm >> 16), (a8[0] + a8[1]) >> 16);
+                if (__ballot(need && pmin2 <= (best >> 16)) == 0) { rows_dropped++; return; }
             }
+#pragma unroll
+            for (int i = 2; i < 6; i++) row_pair(2 * (i - 2) + 1, i & 1, rest[i][0], rest[i][1]);
             // whole-row sums: 64 pixels <= 16320 per field, still no carry between the u16 fields
             const uint32_t l0 = (uint32_t)alo[0] + (uint32_t)alo[1], l1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
             const uint32_t h0 = (uint32_t)ahi[0] + (uint32_t)ahi[1], h1 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
@@ -309,7 +321,14 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
             const int rest = k - 2 * pairs;                   // one-sided tail
             return below > above ? start - pairs - rest : start + pairs + rest;
         };
-        if (__ballot(need) != 0) {
+        // When the previous strip of this wave could drop (almost) nothing -- noise-dominated
+        // images -- the exhaustive code is the faster way to evaluate everything: use it for
+        // the remaining strips of this workgroup.
+        const bool fall_back = __builtin_amdgcn_readfirstlane(prune_pays) == 0;
+        if (fall_back) {
+            exhaustive = true;  // and stays so for the rest of this workgroup's strips
+        } else if (__ballot(need) != 0) {
+            rows_dropped = 0;
             fetch(head_a, order(0));
             for (int k = 0; k < 9; k += 2) {
                 if (k + 1 < 9) fetch(head_b, order(k + 1));
@@ -322,8 +341,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
             const unsigned long long needing = __ballot(need);
             const int src = __ffsll((long long)needing) - 1;
             start_row = (int)((uint32_t)__shfl((int)best, src, 64) & 0xFFFFu) / 9;
+            prune_pays = rows_dropped >= 2;
         }
-    } else {
+    }
+    // The data-independent search: all nine dy rows, all eight row pairs (the whole kernel in
+    // exhaustive mode; the per-wave fallback of the pruned mode when nothing can be pruned).
+    if (exhaustive) {
     // accumulators: per dy, offsets 0..3 / 4..7 packed u16, offset 8 as (sad<<16 | idx)
     u64 acc_lo[DYG], acc_hi[DYG];
     uint32_t acc_8[DYG];
