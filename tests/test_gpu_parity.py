@@ -548,3 +548,30 @@ def test_maximum_frame_size_and_sum_range(aof, orc, gpu_device):
     gb, gf = aof.blocks_view(blocks)[0], aof.flows_view(flows)[0]
     assert gb.tobytes() == ref["blocks"].tobytes() and gf.tobytes() == ref["flow"].tobytes()
     assert gf["flow_x"] == 3 and gf["flow_y"] == -2 and gf["count"] > 100
+
+
+def test_two_contexts_on_two_streams(aof, orc, synth, gpu_device):
+    """Two engines with different configurations enqueue on two HIP streams at once
+    (a multi-camera server); nothing in a context is shared, results stay bit-exact."""
+    import torch
+    pa = aof.default_params(640, 480)
+    pb = aof.default_params(320, 240, pyramid_levels=2, mean_subtract=1)
+    ea, eb = aof.FlowEngine(pa, 0), aof.FlowEngine(pb, 0)
+    eb.set_search_mode(aof.SEARCH_PRUNED)
+    a_prev, a_cur, _ = synth.make_batch(640, 480, 6, 4, 6100, noise=3)
+    b_prev, b_cur, _ = synth.make_batch(320, 240, 9, 9, 6200, noise=3, brightness=7)
+    ta = [torch.from_numpy(x).to(gpu_device) for x in (a_prev, a_cur)]
+    tb = [torch.from_numpy(x).to(gpu_device) for x in (b_prev, b_cur)]
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        with torch.cuda.stream(sa):
+            ra = ea.flow_batch(ta[0], ta[1])
+        with torch.cuda.stream(sb):
+            rb = eb.flow_batch(tb[0], tb[1])
+        outs.append((ra, rb))
+    torch.cuda.synchronize()
+    (ba, fa, _), (bb, fb, _) = outs[-1]
+    check_against_oracle(aof, orc, pa, a_prev, a_cur, dict(blocks=aof.blocks_view(ba), flows=aof.flows_view(fa)))
+    check_against_oracle(aof, orc, pb, b_prev, b_cur, dict(blocks=aof.blocks_view(bb), flows=aof.flows_view(fb)))
