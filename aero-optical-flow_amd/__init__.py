@@ -108,6 +108,7 @@ def _load():
         "aof_exposure_msv": (C.c_float, [VP]),
         "aof_exposure_bin": (C.c_int, [C.c_int]),
         "aof_set_profiling": (C.c_int, [VP, C.c_int]),
+        "aof_set_profiling_mask": (C.c_int, [VP, C.c_uint32]),
         "aof_kernel_ms": (C.c_int, [VP, C.c_int, P(C.c_float)]),
         "aof_profile_count": (C.c_int, [VP, C.c_int]),
         "aof_profile_ms": (C.c_int, [VP, C.c_int, C.c_int, P(C.c_float)]),
@@ -250,8 +251,15 @@ class FlowEngine:
         """SEARCH_EXHAUSTIVE (default) or SEARCH_PRUNED (exact, data-dependent rate)."""
         self._check(lib.aof_set_search_mode(self._ctx, int(mode)))
 
-    def set_profiling(self, on=True):
-        self._check(lib.aof_set_profiling(self._ctx, int(on)))
+    def set_profiling(self, on=True, kernels=None):
+        """Time every kernel (kernels=None) or only the given kernel ids with HIP events."""
+        if on and kernels is not None:
+            mask = 0
+            for k in kernels:
+                mask |= 1 << k
+            self._check(lib.aof_set_profiling_mask(self._ctx, mask))
+        else:
+            self._check(lib.aof_set_profiling(self._ctx, int(on)))
 
     def kernel_ms(self, kernel_id) -> float:
         ms = C.c_float()

@@ -26,6 +26,7 @@ struct aof_ctx {
     int device;
     bool force_generic;
     bool profiling;
+    uint32_t profile_mask;
     int search_mode;
     const char *variant;
     char err[256];
@@ -75,13 +76,13 @@ struct Timed {
     aof_ctx *ctx; int id; hipStream_t s; int slot;
     Timed(aof_ctx *c, int k, hipStream_t st) : ctx(c), id(k), s(st), slot(0)
     {
-        if (!ctx->profiling || ctx->capturing) return;
+        if (!ctx->profiling || ctx->capturing || !((ctx->profile_mask >> id) & 1u)) return;
         slot = (int)(ctx->ev_count[id] % AOF_PROFILE_RING);
         (void)hipEventRecord(ctx->ev[id][slot][0], s);
     }
     ~Timed()
     {
-        if (!ctx->profiling || ctx->capturing) return;
+        if (!ctx->profiling || ctx->capturing || !((ctx->profile_mask >> id) & 1u)) return;
         (void)hipEventRecord(ctx->ev[id][slot][1], s);
         ctx->ev_count[id]++;
     }
@@ -230,7 +231,16 @@ int aof_set_profiling(aof_ctx *ctx, int on)
                 for (int e = 0; e < 2; e++) HIP_TRY(ctx, hipEventCreate(&ctx->ev[k][r][e]));
     }
     ctx->profiling = on != 0;
+    ctx->profile_mask = 0xFFFFFFFFu;
     if (on) for (int k = 0; k < AOF_K_COUNT; k++) ctx->ev_count[k] = 0;
+    return 0;
+}
+
+int aof_set_profiling_mask(aof_ctx *ctx, uint32_t mask)
+{
+    int rc = aof_set_profiling(ctx, mask != 0);
+    if (rc) return rc;
+    ctx->profile_mask = mask;
     return 0;
 }
 

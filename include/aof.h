@@ -215,6 +215,9 @@ int aof_derotate_batch_device(const aof_derotate_params *p, const aof_flow *d_fl
  * Turning profiling on resets the ring. */
 #define AOF_PROFILE_RING 256
 int aof_set_profiling(aof_ctx *ctx, int on);
+/* Same, for a subset: bit k of `mask` times kernel id k (events cost a few microseconds of
+ * stream serialisation each, so a benchmark times only the kernel it prices). */
+int aof_set_profiling_mask(aof_ctx *ctx, uint32_t mask);
 int aof_kernel_ms(aof_ctx *ctx, int kernel_id, float *ms);
 int aof_profile_count(const aof_ctx *ctx, int kernel_id);
 int aof_profile_ms(aof_ctx *ctx, int kernel_id, int index, float *ms);
