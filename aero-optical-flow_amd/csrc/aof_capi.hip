@@ -54,6 +54,18 @@ struct aof_ctx {
 
 namespace {
 
+// The C ABI must not leave the calling thread on another HIP device than it found it on.
+struct DeviceGuard {
+    int prev;
+    explicit DeviceGuard(int device) : prev(-1)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) (void)hipSetDevice(device);
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 int fail(aof_ctx *ctx, int code, const char *fmt, ...)
 {
     if (ctx) {
@@ -142,7 +154,6 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -ENODEV;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return -ENODEV;  // kernels are gfx950 only
-    if (hipSetDevice(device) != hipSuccess) return -ENODEV;
 
     aof_ctx *ctx = new (std::nothrow) aof_ctx();
     if (!ctx) return -ENOMEM;
@@ -164,7 +175,7 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
 void aof_destroy(aof_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     if (ctx->ev) {
         for (int k = 0; k < AOF_K_COUNT; k++)
             for (int r = 0; r < AOF_PROFILE_RING; r++)
@@ -222,8 +233,8 @@ int aof_set_search_mode(aof_ctx *ctx, int mode)
 int aof_set_profiling(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
+    DeviceGuard guard(ctx->device);
     if (on && !ctx->ev) {
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
         ctx->ev = new (std::nothrow) hipEvent_t[AOF_K_COUNT][AOF_PROFILE_RING][2]();
         if (!ctx->ev) return fail(ctx, -ENOMEM, "event ring");
         for (int k = 0; k < AOF_K_COUNT; k++)
@@ -397,7 +408,6 @@ static int ensure_host_state(aof_ctx *ctx)
 {
     if (ctx->d_flow) return 0;
     const aof_params &p = ctx->params;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t frame = (size_t)p.width * p.height;
     aof_ws_layout L;
     aof_workspace_layout(&p, 1, &L);
@@ -473,6 +483,7 @@ int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, ao
 {
     if (!ctx) return -EINVAL;
     if (!prev || !cur || !flow) return fail(ctx, -EINVAL, "null frame or flow pointer");
+    DeviceGuard guard(ctx->device);
     int rc = ensure_host_state(ctx);
     if (rc) return rc;
     const size_t frame = (size_t)ctx->params.width * ctx->params.height;
@@ -488,6 +499,7 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
 {
     if (!ctx) return -EINVAL;
     if (!frame || !flow) return fail(ctx, -EINVAL, "null frame or flow pointer");
+    DeviceGuard guard(ctx->device);
     int rc = ensure_host_state(ctx);
     if (rc) return rc;
     const size_t bytes = (size_t)ctx->params.width * ctx->params.height;

@@ -40,6 +40,9 @@ public:
 
 	// Text of the last engine error ("ok" when healthy); never throws.
 	const char *lastError() const;
+	// False when the GPU engine could not be created (no gfx950 device).  There is no CPU
+	// fallback: calcFlow() then returns -1 for every frame, i.e. nothing is ever published.
+	bool engineOk() const;
 
 protected:
 	OpticalFlow(float f_length_x, float f_length_y, int ouput_rate, int img_width, int img_height);

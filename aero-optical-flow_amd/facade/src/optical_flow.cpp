@@ -27,6 +27,8 @@ OpticalFlow::~OpticalFlow()
 
 const char *OpticalFlow::lastError() const { return _err; }
 
+bool OpticalFlow::engineOk() const { return _ctx != NULL; }
+
 bool OpticalFlow::openEngine(const void *params)
 {
 	const aof_params *p = static_cast<const aof_params *>(params);
@@ -135,6 +137,7 @@ int OpticalFlow::gridTiles() const
 int OpticalFlow::integrate(const uint8_t *img, uint32_t img_time_us, int &dt_us, float &flow_x,
 			   float &flow_y)
 {
+	if (!engineOk()) return -1;  // no engine (no gfx950 device): never publish, see lastError()
 	bool first = false;
 	float px = 0.0f, py = 0.0f;
 	int flow_quality = pixelFlow(img, &px, &py, &first);

@@ -129,3 +129,23 @@ def test_synth_pair_is_a_pure_translation(synth):
     for k in range(4):
         sx, sy = steps[k]
         assert np.array_equal(frames[k + 1][ys, xs], frames[k][ys - sy, xs - sx])
+
+
+def test_facade_without_gpu_never_publishes(aof):
+    """No CPU fallback in the facade either: without a gfx950 device the classes still
+    construct (the reference cannot handle a failing constructor, mainloop.cpp:423-428),
+    say why, and calcFlow() returns -1 for every frame so nothing is published."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    for cls in (aof.OpticalFlowPX4, aof.OpticalFlowOpenCV):
+        flow = cls(216.0, 216.0, 15, 64, 64)
+        assert "no usable gfx950 device" in flow.lastError()
+        assert (flow.getImageWidth(), flow.getImageHeight()) == (64, 64)
+        img = np.zeros((64, 64), np.uint8)
+        t = 0
+        for _ in range(12):
+            assert flow.calcFlow(img, t)[0] == -1
+            t += 13333
+        flow.close()
