@@ -81,7 +81,7 @@ Tile8Plan plan_tile8(int w, int nx, int ny)
 
 bool tile8_geometry(const aof_params &p, int level)
 {
-    if (p.tile != 8 || p.search != 4 || p.subpixel || p.grid_mode != AOF_GRID_DENSE) return false;
+    if (p.tile != 8 || p.search != 4 || p.grid_mode != AOF_GRID_DENSE) return false;
     const int w = p.width >> level;
     if (w % 16) return false;
     Grid g;

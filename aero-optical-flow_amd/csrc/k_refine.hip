@@ -1,0 +1,127 @@
+// K2b -- half-pixel refinement after an LDS-tiled integer search (DESIGN.md "Spec":
+// Half-pixel refinement).
+//
+// The LDS-tiled search kernels keep one result per lane and have no room for the ring of
+// the best match, so on configurations with half-pixel refinement they write the integer
+// records and this pass adds the direction byte.  One lane per block: the lane reads its
+// reference tile and the (B+2)^2 neighbourhood of its best match straight from global
+// memory (both frames were streamed by the search a moment ago and sit in L2), rows as
+// unaligned 8/16-byte loads.  The eight half-pixel images are built four pixels at a time
+// with v_lerp_u8 -- floor((a+b)/2) per byte, the UHADD8 of the published algorithm -- from
+// three row-shifted copies of each window row:
+//   H+(y) = lerp(P(y,x), P(y,x+1))   H-(y) = lerp(P(y,x), P(y,x-1))   C(y) = P(y,x)
+//   dir 0 = H+(y)              dir 4 = H-(y)
+//   dir 2 = lerp(C(y),C(y+1))  dir 6 = lerp(C(y),C(y-1))
+//   dir 1 = lerp(H+(y),H+(y+1))  dir 7 = lerp(H+(y-1),H+(y))
+//   dir 3 = lerp(H-(y),H-(y+1))  dir 5 = lerp(H-(y-1),H-(y))
+// so one pass over window rows y = -1..B with the previous row kept in registers feeds all
+// eight SADs.  Blocks the search skipped or rejected get direction 8 (none).
+#include "aof_device.hpp"
+#include "aof_internal.hpp"
+
+namespace aof {
+
+namespace {
+
+constexpr int kRefineThreads = 256;
+
+template <int NW>  // dwords per tile row: 2 (8x8) or 4 (16x16)
+__global__ __launch_bounds__(kRefineThreads) void k_refine(SearchArgs a)
+{
+    constexpr int B = 4 * NW;
+    const int64_t pair = blockIdx.y + (int64_t)blockIdx.z * gridDim.y;
+    const int blk = blockIdx.x * kRefineThreads + threadIdx.x;
+    const int nb = a.grid.blocks();
+    if (pair >= a.n_pairs || blk >= nb) return;
+    const aof_block rec = a.blocks[pair * nb + blk];
+    uint8_t *out = a.subdirs + pair * nb + blk;
+    if (rec.sad == AOF_SAD_SKIPPED || (uint32_t)rec.sad >= (uint32_t)a.value_threshold) {
+        *out = 8;
+        return;
+    }
+    const int bx = blk % a.grid.nx, by = blk / a.grid.nx;
+    const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y;
+    const int W = a.w;
+    const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(a.w * a.h));
+    const uint8_t *pr = a.prev + pair * a.pair_stride + (int64_t)j * W + i;
+    // window row y = -1 starts one pixel left of the best match (the search kept the whole
+    // ring inside the frame, or the block would have been skipped)
+    const uint8_t *pc = a.cur + pair * a.pair_stride + (int64_t)(j + rec.dy - 1) * W + (i + rec.dx - 1);
+
+    uint32_t ref[B][NW];
+#pragma unroll
+    for (int r = 0; r < B; r++) __builtin_memcpy(ref[r], pr + r * W, 4 * NW);
+
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t pc_[NW], ph_[NW], pl_[NW];  // previous window row: C, H+, H-
+#pragma unroll
+    for (int y = -1; y <= B; y++) {
+        // bytes -1 .. B+1 of the row: NW dwords + one 16-bit tail (never past the ring)
+        uint32_t d[NW + 1];
+        uint16_t tail;
+        __builtin_memcpy(d, pc + (y + 1) * W, 4 * NW);
+        __builtin_memcpy(&tail, pc + (y + 1) * W + 4 * NW, 2);
+        d[NW] = tail;
+        if (delta != 0) {  // uniform over the workgroup (one pair)
+#pragma unroll
+            for (int q = 0; q <= NW; q++) d[q] = sat_add_u8x4(d[q], delta);
+        }
+        uint32_t c[NW], hp[NW], hm[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            c[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
+            const uint32_t right = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+            hp[q] = __builtin_amdgcn_lerp(c[q], right, 0u);
+            hm[q] = __builtin_amdgcn_lerp(c[q], d[q], 0u);
+        }
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            if (y >= 0 && y < B) {
+                acc[0] = __builtin_amdgcn_sad_u8(hp[q], ref[y < B ? (y >= 0 ? y : 0) : 0][q], acc[0]);
+                acc[4] = __builtin_amdgcn_sad_u8(hm[q], ref[y < B ? (y >= 0 ? y : 0) : 0][q], acc[4]);
+            }
+            if (y >= 0) {
+                const uint32_t v = __builtin_amdgcn_lerp(pc_[q], c[q], 0u);
+                const uint32_t dr = __builtin_amdgcn_lerp(ph_[q], hp[q], 0u);
+                const uint32_t dl = __builtin_amdgcn_lerp(pl_[q], hm[q], 0u);
+                if (y >= 1) {  // tile row y-1 looks down
+                    acc[2] = __builtin_amdgcn_sad_u8(v, ref[y >= 1 ? y - 1 : 0][q], acc[2]);
+                    acc[1] = __builtin_amdgcn_sad_u8(dr, ref[y >= 1 ? y - 1 : 0][q], acc[1]);
+                    acc[3] = __builtin_amdgcn_sad_u8(dl, ref[y >= 1 ? y - 1 : 0][q], acc[3]);
+                }
+                if (y < B) {   // tile row y looks up
+                    acc[6] = __builtin_amdgcn_sad_u8(v, ref[y < B ? y : 0][q], acc[6]);
+                    acc[7] = __builtin_amdgcn_sad_u8(dr, ref[y < B ? y : 0][q], acc[7]);
+                    acc[5] = __builtin_amdgcn_sad_u8(dl, ref[y < B ? y : 0][q], acc[5]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NW; q++) { pc_[q] = c[q]; ph_[q] = hp[q]; pl_[q] = hm[q]; }
+    }
+    uint32_t mind = rec.sad;
+    int subdir = 8;
+#pragma unroll
+    for (int dir = 0; dir < 8; dir++)
+        if (acc[dir] < mind) { mind = acc[dir]; subdir = dir; }
+    *out = (uint8_t)subdir;
+}
+
+}  // namespace
+
+int launch_refine(const SearchArgs &a, void *stream)
+{
+    if (a.n_pairs == 0 || !a.subdirs) return 0;
+    const int64_t gy = a.n_pairs < 32768 ? a.n_pairs : 32768;
+    const int64_t gz = (a.n_pairs + gy - 1) / gy;
+    const dim3 grid((uint32_t)((a.grid.blocks() + kRefineThreads - 1) / kRefineThreads), (uint32_t)gy, (uint32_t)gz);
+    if (a.tile == 8)
+        hipLaunchKernelGGL(k_refine<2>, grid, dim3(kRefineThreads), 0, static_cast<hipStream_t>(stream), a);
+    else if (a.tile == 16)
+        hipLaunchKernelGGL(k_refine<4>, grid, dim3(kRefineThreads), 0, static_cast<hipStream_t>(stream), a);
+    else
+        return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+}  // namespace aof

@@ -91,7 +91,11 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     int start_row = 4;                                // dy index visited first (wave-uniform)
     int prune_pays = 1;                               // previous strip of this wave dropped rows
     for (int strip = first_strip; strip < min(nstrips, first_strip + spw); strip++) {
-    const int W = a.w, H = a.h, nx = a.grid.nx, ny = a.grid.ny;
+    // With half-pixel refinement the grid origin is S+1 = 5: the same geometry as the S = 4
+    // grid on a frame whose origin is moved by (1, 1).  Rows keep the pitch W; windows must
+    // stay inside [0, W-2) x [0, H-2) of the moved frame (one pixel of ring on every side).
+    const int org = a.grid.x0 - 4;                    // 0, or 1 with the half-pixel margin
+    const int W = a.w, H = a.h - 2 * org, Wb = a.w - 2 * org, nx = a.grid.nx, ny = a.grid.ny;
     const int by0 = strip * rb;
     const int rows = min(rb, ny - by0);
     const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     int px = 0, py = 0;
     if (SHIFTED) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
 
-    const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * H));
+    const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(a.w * a.h));
 
     // ---- stage the strip into LDS (flat 16-byte copies) ----
     const int n_cur_rows = 8 * rows + 8;
@@ -112,17 +116,18 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     uint32_t *s_hist = s_best + rb * nx;            // [2][bins] votes of this strip
     const int centre = 2 * a.hist_range + 1, bins = 2 * centre + 1;
     const int sh7 = SHIFTED ? (px & 7) : 0;        // floor-mod: px = 8*(px >> 3) + sh7
-    const uint8_t *g_cur = a.cur + pair * a.pair_stride + (int64_t)(yc0 + r_lo) * W + sh7;
-    const uint8_t *g_prev = a.prev + pair * a.pair_stride + (int64_t)(8 * by0 + 4) * W;
+    const int64_t org_off = (int64_t)org * (W + 1);  // moved frame origin, in bytes
+    const uint8_t *g_cur = a.cur + pair * a.pair_stride + org_off + (int64_t)(yc0 + r_lo) * W + sh7;
+    const uint8_t *g_prev = a.prev + pair * a.pair_stride + org_off + (int64_t)(8 * by0 + 4) * W;
     int cur_chunks = r_hi > r_lo ? (r_hi - r_lo) * (W / 16) : 0;
     const int prev_chunks = 8 * rows * (W / 16);
     // The pre-shifted copy runs sh7 bytes past its last row; when that row is the last
     // row of the frame the final chunk is copied bytewise with a bounds check instead.
-    const bool tail_guard = SHIFTED && sh7 != 0 && cur_chunks > 0 && yc0 + r_hi == H;
+    const bool tail_guard = SHIFTED && sh7 != 0 && cur_chunks > 0 && org == 0 && yc0 + r_hi == H;
     if (tail_guard) cur_chunks -= 1;
     if (LAB_MODE == 1) {
         // lab: no global traffic
-    } else if (!SHIFTED && delta == 0) {
+    } else if (!SHIFTED && delta == 0 && org == 0) {
         uint8_t *dst = s_cur + r_lo * W;
         // LDS-DMA: each wave-instruction moves 1 KiB global -> LDS without touching VGPRs
         // (destination = wave-uniform base + lane*16, so the flat copy maps 1:1)
@@ -151,7 +156,13 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
             s_cur[r_lo * W + cur_chunks * 16 + tid] =
                 (uint8_t)clamp_u8((int)g_cur[cur_chunks * 16 + tid] + delta);
     }
-    if (LAB_MODE != 1) {
+    if (LAB_MODE != 1 && org != 0) {  // moved origin: byte-aligned source, through registers
+        for (int c = tid; c < prev_chunks; c += nthreads) {
+            uint4 v;
+            __builtin_memcpy(&v, g_prev + c * 16, 16);
+            *reinterpret_cast<uint4 *>(s_prev + c * 16) = v;
+        }
+    } else if (LAB_MODE != 1) {
         const uint32_t wbase = (uint32_t)(tid & ~63) * 16u, lane16 = (uint32_t)(tid & 63) * 16u;
         const uint32_t total = (uint32_t)prev_chunks * 16u, step = (uint32_t)nthreads * 16u;
         uint32_t o = wbase;
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     int xs = 8 * bx;                              // LDS byte column of the window start
     if (SHIFTED) {
         const int xf = 8 * bx + px;               // frame column of the window start
-        inside = xf >= 0 && xf + 16 <= W && 8 * brow >= r_lo && 8 * brow + 16 <= r_hi;
+        inside = xf >= 0 && xf + 16 <= Wb && 8 * brow >= r_lo && 8 * brow + 16 <= r_hi;
         xs = inside ? xf - sh7 : 0;               // 8-aligned; ignored reads stay in range
     }
 
@@ -427,8 +438,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
 
 bool tile8_supported(const SearchArgs &a)
 {
-    if (a.tile != 8 || a.search != 4 || a.subpixel) return false;
-    if (a.grid.x0 != 4 || a.grid.y0 != 4 || a.grid.step_x != 8 || a.grid.step_y != 8) return false;
+    if (a.tile != 8 || a.search != 4) return false;
+    // dense grid at origin S (integer search) or S+1 (a half-pixel refinement pass follows)
+    const int org = a.subpixel ? 1 : 0;
+    if (a.grid.x0 != 4 + org || a.grid.y0 != 4 + org || a.grid.step_x != 8 || a.grid.step_y != 8) return false;
     if (a.w % 16 || a.pair_stride % 16) return false;
     if (reinterpret_cast<uintptr_t>(a.prev) % 16 || reinterpret_cast<uintptr_t>(a.cur) % 16) return false;
     if ((int64_t)a.w * a.h > 0x7FFFFFFF) return false;

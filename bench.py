@@ -35,6 +35,8 @@ WORKLOADS = {
            640, 480, dict(), 4),
     "c3": ("C3 640x480, 2-level mean-subtracted pyramid + 4x4 gate/histogram filter",
            640, 480, dict(pyramid_levels=2, mean_subtract=1), 9),
+    "c2h": ("C2 geometry with half-pixel refinement on the dense grid (origin 5, 4582 blocks/pair)",
+            640, 480, dict(subpixel=1), 4),
     "c5": ("C5 1280x960 pairs, 16x16 SAD, +-8 search",
            1280, 960, dict(tile=16, search=8, value_threshold=12000), 8),
 }

@@ -170,7 +170,9 @@ SHAPES = [
     dict(width=160, height=128, pyramid_levels=2),                # shifted tile8 path
     dict(width=160, height=128, pyramid_levels=2, mean_subtract=1, hist_filter=0),
     dict(width=100, height=90, mean_subtract=1),                  # sums via the scalar K1 path
-    dict(width=128, height=96, subpixel=1),                       # dense + half-pixel -> generic
+    dict(width=128, height=96, subpixel=1),                       # dense + half-pixel: tile8 + refine pass
+    dict(width=160, height=128, subpixel=1, pyramid_levels=2, mean_subtract=1),
+    dict(width=160, height=130, subpixel=1, pyramid_levels=2),    # shifted path, odd level-1 height
     dict(width=128, height=128, grid_mode=1, subpixel=1, num_blocks=7),
     dict(width=128, height=96, grid_mode=1, subpixel=1, pyramid_levels=2, mean_subtract=1),
     dict(width=96, height=96, tile=16, search=8, value_threshold=12000),
@@ -202,6 +204,33 @@ def test_shapes_and_options(aof, orc, synth, gpu_device, case):
     got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
     check_against_oracle(aof, orc, p, prevs, curs, got,
                          subdirs=sub.cpu().numpy() if sub is not None else None)
+
+
+@pytest.mark.parametrize("mode", ["exhaustive", "pruned", "generic"])
+@pytest.mark.parametrize("kw", [dict(), dict(pyramid_levels=2, mean_subtract=1)])
+def test_vga_dense_half_pixel(aof, orc, synth, gpu_device, mode, kw):
+    """Dense grid with half-pixel refinement (origin S+1): the LDS-tiled integer search on the
+    moved origin plus the refinement pass must equal the oracle, every direction exercised."""
+    import torch
+    p = aof.default_params(640, 480, subpixel=1, **kw)
+    n = 10
+    prevs, curs, _ = synth.make_batch(640, 480, n, 4, 4100, noise=3, brightness=5 if kw else 0)
+    for i, half in enumerate([(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1), (1, -1), (-1, 1)]):
+        prevs[i], curs[i], _ = synth.make_pair(640, 480, 4, 50 + i, shift=(2 - i % 5, i % 3 - 1), half=half)
+    eng = aof.FlowEngine(p, 0)
+    assert eng.variant == "tile8_lds"
+    if mode == "generic":
+        eng.force_generic(True)
+    elif mode == "pruned":
+        eng.set_search_mode(aof.SEARCH_PRUNED)
+    tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
+    sub = torch.full((n, eng.nblocks(0)), 99, dtype=torch.uint8, device=gpu_device)
+    blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+    torch.cuda.synchronize()
+    got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
+    check_against_oracle(aof, orc, p, prevs, curs, got, subdirs=sub.cpu().numpy())
+    seen = set(np.unique(sub.cpu().numpy()[:8]))
+    assert seen >= {0, 1, 2, 3, 4, 5, 6, 7}, seen
 
 
 def test_flat_and_saturated_frames(aof, orc, gpu_device):
