@@ -136,7 +136,10 @@ int run_search(aof_ctx *ctx, SearchArgs a, uint32_t *parts, const uint32_t **par
         }
         rc = launch_search_tile8(a, s);
         if (!rc && a.subpixel) rc = launch_refine(a, s);  // adds the half-pixel directions
-    } else if (!ctx->force_generic && tile16_supported(a)) rc = launch_search_tile16(a, s);
+    } else if (!ctx->force_generic && tile16_supported(a)) {
+        rc = launch_search_tile16(a, s);
+        if (!rc && a.subpixel) rc = launch_refine(a, s);
+    }
     else rc = launch_search_generic(a, s);
     if (rc) return fail(ctx, -EIO, "search launch: %s", hipGetErrorString((hipError_t)rc));
     return 0;

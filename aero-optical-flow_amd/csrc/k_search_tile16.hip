@@ -42,10 +42,27 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     uint8_t *s_cur = smem;                           // frame rows [16*by, 16*by + 32)
     uint8_t *s_prev = smem + (size_t)32 * W;         // frame rows [16*by + 8, +16)
     uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + (size_t)48 * W);
-    const uint8_t *g_cur = a.cur + pair * a.pair_stride + (int64_t)(16 * by) * W;
-    const uint8_t *g_prev = a.prev + pair * a.pair_stride + (int64_t)(16 * by + 8) * W;
+    // Half-pixel refinement moves the grid origin to S+1 = 9: the same geometry on a frame whose
+    // origin is moved by (1, 1) -- the flat copies start W+1 bytes later (byte-aligned loads);
+    // the grid keeps every window inside the smaller frame.  K2b adds the directions.
+    const int org = a.grid.x0 - 8;
+    const int64_t org_off = (int64_t)org * (W + 1);
+    const uint8_t *g_cur = a.cur + pair * a.pair_stride + org_off + (int64_t)(16 * by) * W;
+    const uint8_t *g_prev = a.prev + pair * a.pair_stride + org_off + (int64_t)(16 * by + 8) * W;
     const int cur_chunks = 32 * (W / 16), prev_chunks = 16 * (W / 16);
-    if (delta == 0) {
+    if (org != 0) {
+        for (int c = tid; c < cur_chunks + prev_chunks; c += kThreads) {
+            const bool is_cur = c < cur_chunks;
+            const int cc = is_cur ? c : c - cur_chunks;
+            uint4 v;
+            __builtin_memcpy(&v, (is_cur ? g_cur : g_prev) + (size_t)cc * 16, 16);
+            if (is_cur && delta != 0) {
+                v.x = sat_add_u8x4(v.x, delta); v.y = sat_add_u8x4(v.y, delta);
+                v.z = sat_add_u8x4(v.z, delta); v.w = sat_add_u8x4(v.w, delta);
+            }
+            *reinterpret_cast<uint4 *>((is_cur ? s_cur : s_prev) + (size_t)cc * 16) = v;
+        }
+    } else if (delta == 0) {
         for (int c = tid; c < cur_chunks; c += kThreads)
             *reinterpret_cast<uint4 *>(s_cur + (size_t)c * 16) =
                 *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
@@ -57,9 +74,10 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
             *reinterpret_cast<uint4 *>(s_cur + (size_t)c * 16) = v;
         }
     }
-    for (int c = tid; c < prev_chunks; c += kThreads)
-        *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) =
-            *reinterpret_cast<const uint4 *>(g_prev + (size_t)c * 16);
+    if (org == 0)
+        for (int c = tid; c < prev_chunks; c += kThreads)
+            *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) =
+                *reinterpret_cast<const uint4 *>(g_prev + (size_t)c * 16);
     for (int b = tid; b < nx; b += kThreads) s_best[b] = 0xFFFFFFFFu;
     __syncthreads();
 
@@ -139,8 +157,9 @@ size_t tile16_lds(const SearchArgs &a) { return (size_t)48 * a.w + 4 * (size_t)a
 
 bool tile16_supported(const SearchArgs &a)
 {
-    if (a.tile != 16 || a.search != 8 || a.subpixel || a.pred) return false;
-    if (a.grid.x0 != 8 || a.grid.y0 != 8 || a.grid.step_x != 16 || a.grid.step_y != 16) return false;
+    if (a.tile != 16 || a.search != 8 || a.pred) return false;
+    const int org = a.subpixel ? 1 : 0;  // origin S+1: K2b follows
+    if (a.grid.x0 != 8 + org || a.grid.y0 != 8 + org || a.grid.step_x != 16 || a.grid.step_y != 16) return false;
     if (a.w % 16 || a.pair_stride % 16) return false;
     if (reinterpret_cast<uintptr_t>(a.prev) % 16 || reinterpret_cast<uintptr_t>(a.cur) % 16) return false;
     if ((int64_t)a.w * a.h > 0x7FFFFFFF) return false;

@@ -39,6 +39,8 @@ WORKLOADS = {
             640, 480, dict(subpixel=1), 4),
     "c5": ("C5 1280x960 pairs, 16x16 SAD, +-8 search",
            1280, 960, dict(tile=16, search=8, value_threshold=12000), 8),
+    "c5h": ("C5 geometry with half-pixel refinement (origin 9)",
+            1280, 960, dict(tile=16, search=8, value_threshold=12000, subpixel=1), 8),
 }
 
 
@@ -355,7 +357,7 @@ def main():
             traffic = None
 
     out = {
-        "metric": "frame-pairs/s (640x480, 8x8 SAD, +-4 search)" if args.workload != "c5"
+        "metric": "frame-pairs/s (640x480, 8x8 SAD, +-4 search)" if not args.workload.startswith("c5")
                   else "frame-pairs/s (1280x960, 16x16 SAD, +-8 search)",
         "value": round(world * n * args.steps / elapsed, 1),
         "unit": "frame-pairs/s",

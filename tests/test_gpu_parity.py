@@ -177,6 +177,8 @@ SHAPES = [
     dict(width=128, height=96, grid_mode=1, subpixel=1, pyramid_levels=2, mean_subtract=1),
     dict(width=96, height=96, tile=16, search=8, value_threshold=12000),
     dict(width=96, height=96, tile=16, search=5, value_threshold=12000, subpixel=1),
+    dict(width=160, height=128, tile=16, search=8, value_threshold=12000, subpixel=1),   # tile16 + refine
+    dict(width=160, height=130, tile=16, search=8, value_threshold=12000, subpixel=1, mean_subtract=1),
     dict(width=80, height=64, search=2),
     dict(width=80, height=64, search=7, min_valid=0),
     dict(width=1280, height=64),                                  # wide rows: strip planning
