@@ -8,7 +8,6 @@
 namespace aof {
 
 typedef unsigned long long u64;
-typedef short short2_t __attribute__((ext_vector_type(2)));
 
 // Spec "Mean": round-half-up integer mean; delta = mean(prev) - mean(cur).
 // sums layout: [pair][frame: 0 prev, 1 cur][level].
@@ -25,20 +24,48 @@ __device__ __forceinline__ int equalise_delta(const uint32_t *sums, int64_t pair
 
 __device__ __forceinline__ int clamp_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
-// clamp(b + delta, 0, 255) on four packed bytes: widen to two packed-i16 pairs
-// (v_perm_b32), v_pk_add/max/min_i16, narrow again (v_perm_b32).
+// clamp(b + delta, 0, 255) on four packed bytes in four instructions.  A byte sitting in the HIGH
+// half of a u16 lane saturates exactly like a u8 under v_pk_add_u16 / v_pk_sub_u16 with clamp
+// (the addend delta<<8 leaves the low half alone): the odd bytes already sit there, the even
+// bytes after a shift by 8, and one v_perm_b32 gathers the four high halves.
+// d8 = |delta| in the high byte of both u16 lanes (sat_delta_u16x2).
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t sat_delta_u16x2(int delta)
+{
+    const uint32_t m = (uint32_t)(delta < 0 ? -delta : delta);
+    return (m << 8) | (m << 24);
+}
+
+template <bool NEG>
+__device__ __forceinline__ uint32_t sat_shift_u8x4(uint32_t v, uint32_t d8)
+{
+    const ushort2_t odd = __builtin_bit_cast(ushort2_t, v), even = __builtin_bit_cast(ushort2_t, v << 8);
+    const ushort2_t d = __builtin_bit_cast(ushort2_t, d8);
+    const ushort2_t o2 = NEG ? __builtin_elementwise_sub_sat(odd, d) : __builtin_elementwise_add_sat(odd, d);
+    const ushort2_t e2 = NEG ? __builtin_elementwise_sub_sat(even, d) : __builtin_elementwise_add_sat(even, d);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, o2), __builtin_bit_cast(uint32_t, e2),
+                                 0x07030501u);
+}
+
+// delta is wave-uniform at every call site: the branch is scalar.
 __device__ __forceinline__ uint32_t sat_add_u8x4(uint32_t v, int delta)
 {
-    const uint32_t lo = __builtin_amdgcn_perm(0u, v, 0x0c010c00u);  // b1:b0 as i16 pair
-    const uint32_t hi = __builtin_amdgcn_perm(0u, v, 0x0c030c02u);  // b3:b2
-    const short2_t d = {(short)delta, (short)delta};
-    const short2_t zero = {0, 0}, top = {255, 255};
-    short2_t l = __builtin_bit_cast(short2_t, lo) + d;
-    short2_t h = __builtin_bit_cast(short2_t, hi) + d;
-    l = __builtin_elementwise_min(__builtin_elementwise_max(l, zero), top);
-    h = __builtin_elementwise_min(__builtin_elementwise_max(h, zero), top);
-    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h), __builtin_bit_cast(uint32_t, l),
-                                 0x06040200u);
+    const uint32_t d8 = sat_delta_u16x2(delta);
+    return delta < 0 ? sat_shift_u8x4<true>(v, d8) : sat_shift_u8x4<false>(v, d8);
+}
+
+__device__ __forceinline__ uint4 sat_add_u8x16(uint4 v, int delta)
+{
+    const uint32_t d8 = sat_delta_u16x2(delta);
+    if (delta < 0) {
+        v.x = sat_shift_u8x4<true>(v.x, d8); v.y = sat_shift_u8x4<true>(v.y, d8);
+        v.z = sat_shift_u8x4<true>(v.z, d8); v.w = sat_shift_u8x4<true>(v.w, d8);
+    } else {
+        v.x = sat_shift_u8x4<false>(v.x, d8); v.y = sat_shift_u8x4<false>(v.y, d8);
+        v.z = sat_shift_u8x4<false>(v.z, d8); v.w = sat_shift_u8x4<false>(v.w, d8);
+    }
+    return v;
 }
 
 // Sum of the four bytes of w added to acc (v_sad_u8 against zero).

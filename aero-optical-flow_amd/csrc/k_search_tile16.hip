@@ -57,8 +57,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
             uint4 v;
             __builtin_memcpy(&v, (is_cur ? g_cur : g_prev) + (size_t)cc * 16, 16);
             if (is_cur && delta != 0) {
-                v.x = sat_add_u8x4(v.x, delta); v.y = sat_add_u8x4(v.y, delta);
-                v.z = sat_add_u8x4(v.z, delta); v.w = sat_add_u8x4(v.w, delta);
+                v = sat_add_u8x16(v, delta);
             }
             *reinterpret_cast<uint4 *>((is_cur ? s_cur : s_prev) + (size_t)cc * 16) = v;
         }
@@ -69,8 +68,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     } else {
         for (int c = tid; c < cur_chunks; c += kThreads) {
             uint4 v = *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
-            v.x = sat_add_u8x4(v.x, delta); v.y = sat_add_u8x4(v.y, delta);
-            v.z = sat_add_u8x4(v.z, delta); v.w = sat_add_u8x4(v.w, delta);
+            v = sat_add_u8x16(v, delta);
             *reinterpret_cast<uint4 *>(s_cur + (size_t)c * 16) = v;
         }
     }

@@ -147,8 +147,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
             uint4 v;  // 16-B load from a byte-aligned address (gfx950 handles unaligned global loads)
             __builtin_memcpy(&v, g_cur + c * 16, 16);
             if (delta != 0) {
-                v.x = sat_add_u8x4(v.x, delta); v.y = sat_add_u8x4(v.y, delta);
-                v.z = sat_add_u8x4(v.z, delta); v.w = sat_add_u8x4(v.w, delta);
+                v = sat_add_u8x16(v, delta);
             }
             *reinterpret_cast<uint4 *>(s_cur + r_lo * W + c * 16) = v;
         }
