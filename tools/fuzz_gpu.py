@@ -20,12 +20,13 @@ synth = importlib.import_module("aero_optical_flow_amd.synth")
 
 
 def case(rng):
-    fast = rng.random() < 0.7
-    tile = 8 if fast or rng.random() < 0.5 else 16
-    search = 4 if fast else int(rng.choice([8 if tile == 16 else 4, rng.integers(1, 9)]))
+    fast = rng.random() < 0.7          # geometries the LDS-tiled kernels serve
+    fast16 = fast and rng.random() < 0.2
+    tile = (16 if fast16 else 8) if fast or rng.random() < 0.5 else 16
+    search = (8 if fast16 else 4) if fast else int(rng.choice([8 if tile == 16 else 4, rng.integers(1, 9)]))
     levels = int(rng.choice([1, 1, 2]))
     grid_mode = 0 if fast else int(rng.choice([0, 1]))
-    subpixel = 0 if fast else (1 if grid_mode else int(rng.integers(0, 2)))
+    subpixel = int(rng.random() < 0.35) if fast else (1 if grid_mode else int(rng.integers(0, 2)))
     min_dim = (tile + 2 * (search + 1) + 8) * (2 if levels == 2 else 1)
     w = int(rng.integers(min_dim, min_dim + 400))
     h = int(rng.integers(min_dim, min_dim + 200))
@@ -57,7 +58,12 @@ def main():
         n = 2
         prevs, curs, _ = synth.make_batch(p.width, p.height, n, reach, 90000 + 3 * s, noise=int(rng.choice([0, 0, 3, 25])),
                                           brightness=int(rng.integers(-40, 41)), contrast=float(rng.choice([1.0, 1.0, 3.0, 0.15])))
-        style = int(rng.integers(0, 6))
+        style = int(rng.integers(0, 7))
+        if style == 5:  # half-pixel displaced pair: every refinement direction gets its turn
+            half = [(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1), (1, -1), (-1, 1)][s % 8]
+            sh = (int(rng.integers(-p.search + 1, p.search)), int(rng.integers(-p.search + 1, p.search)))
+            if p.pyramid_levels == 1:
+                prevs[0], curs[0], _ = synth.make_pair(p.width, p.height, p.search, 7000 + s, shift=sh, half=half)
         if style == 1:
             curs[0] = rng.integers(0, 256, curs[0].shape, dtype=np.uint8)
         elif style == 2:
