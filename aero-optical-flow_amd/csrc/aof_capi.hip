@@ -139,6 +139,9 @@ int run_search(aof_ctx *ctx, SearchArgs a, uint32_t *parts, const uint32_t **par
     } else if (!ctx->force_generic && tile16_supported(a)) {
         rc = launch_search_tile16(a, s);
         if (!rc && a.subpixel) rc = launch_refine(a, s);
+    } else if (!ctx->force_generic && lane8_supported(a)) {
+        rc = launch_search_lane8(a, s);
+        if (!rc && a.subpixel) rc = launch_refine(a, s);
     }
     else rc = launch_search_generic(a, s);
     if (rc) return fail(ctx, -EIO, "search launch: %s", hipGetErrorString((hipError_t)rc));
@@ -173,7 +176,8 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
     // which search kernel will level 0 use? (probe with aligned dummy pointers)
     SearchArgs probe = search_args(ctx, 0, nullptr, nullptr, (int64_t)p->width * p->height, nullptr,
                                    nullptr, nullptr, nullptr, 1);
-    ctx->variant = tile8_supported(probe) ? "tile8_lds" : (tile16_supported(probe) ? "tile16_lds" : "generic");
+    ctx->variant = tile8_supported(probe) ? "tile8_lds"
+                   : (tile16_supported(probe) ? "tile16_lds" : (lane8_supported(probe) ? "lane8" : "generic"));
     *out = ctx;
     return 0;
 }
@@ -308,6 +312,8 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         return fail(ctx, -ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, L.total_bytes);
     if (reinterpret_cast<uintptr_t>(d_workspace) % 256)
         return fail(ctx, -EINVAL, "workspace must be 256-byte aligned");
+    if (reinterpret_cast<uintptr_t>(d_blocks) % 4 || reinterpret_cast<uintptr_t>(d_flows) % 4)
+        return fail(ctx, -EINVAL, "block and flow records must be 4-byte aligned");
     int cur_dev = -1;
     if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev != ctx->device)
         return fail(ctx, -EINVAL, "context was created for device %d but the calling thread's current "

@@ -91,6 +91,11 @@ int launch_refine(const SearchArgs &a, void *stream);
 // half-pixel refinement.  tile8_supported() says whether `a` qualifies.
 bool tile8_supported(const SearchArgs &a);
 int launch_search_tile8(const SearchArgs &a, void *stream);
+// Lane-per-block kernel straight from global memory for B=8, S=4 on ANY grid / width /
+// predictor (sparse PX4Flow grid, rows that are no multiple of 16 bytes).  Integer search only:
+// K2b adds the half-pixel directions.
+bool lane8_supported(const SearchArgs &a);
+int launch_search_lane8(const SearchArgs &a, void *stream);
 // LDS-tiled (block, dy)-per-lane kernel for B=16, S=8 on a dense grid, no predictor.
 bool tile16_supported(const SearchArgs &a);
 int launch_search_tile16(const SearchArgs &a, void *stream);

@@ -39,21 +39,32 @@ __device__ __forceinline__ long long floor_div(long long a, long long b)
     return q;
 }
 
+// GROUP = threads per pair: 256 (one workgroup per pair) or 64 (one wave per pair, four pairs
+// per workgroup: sparse grids with a few dozen blocks per pair, where a whole workgroup per
+// pair is mostly launch overhead).  A wave-sized group needs no workgroup barrier: its LDS
+// operations retire in program order.
+template <int GROUP>
 __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
 {
-    __shared__ uint32_t hist[2][kMaxHist];
-    __shared__ int sums[3];  // sum2x, sum2y, count
-    const int64_t pair = blockIdx.x;
+    constexpr int kGroups = kThreads / GROUP;
+    __shared__ uint32_t s_hist[kGroups][2][kMaxHist];
+    __shared__ int s_sums[kGroups][3];  // sum2x, sum2y, count
+    const int grp = (int)threadIdx.x / GROUP, tid = (int)threadIdx.x % GROUP;
+    const int64_t pair = (int64_t)blockIdx.x * kGroups + grp;
+    if (GROUP < kThreads && pair >= a.n_pairs) return;  // whole waves only: no barrier is skipped
+    auto sync = [] { if (GROUP == kThreads) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    uint32_t (*hist)[kMaxHist] = s_hist[grp];
+    int *sums = s_sums[grp];
     const int centre = 2 * a.range + 1, n = 2 * centre + 1;
-    for (int k = threadIdx.x; k < n; k += kThreads) { hist[0][k] = 0; hist[1][k] = 0; }
-    if (threadIdx.x < 3) sums[threadIdx.x] = 0;
-    __syncthreads();
+    for (int k = tid; k < n; k += GROUP) { hist[0][k] = 0; hist[1][k] = 0; }
+    if (tid < 3) sums[tid] = 0;
+    sync();
 
     if (a.parts) {
         // The tile8 search already voted per strip: sum the strips' histograms.  Count and
         // shift sums follow from the histogram: count = sum h[k], sum2 = sum (k - centre) h[k].
         const uint32_t *parts = a.parts + (size_t)pair * a.nstrips * (size_t)(2 * n);
-        for (int k = threadIdx.x; k < 2 * n; k += kThreads) {
+        for (int k = tid; k < 2 * n; k += GROUP) {
             uint32_t v = 0;
             for (int st = 0; st < a.nstrips; st++) v += parts[(size_t)st * (2 * n) + k];
             const int axis = k >= n, bin = k - axis * n;
@@ -63,12 +74,12 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
                 if (!axis) atomicAdd(&sums[2], (int)v);
             }
         }
-        __syncthreads();
+        sync();
     } else {
     const aof_block *blocks = a.blocks + pair * a.nblocks;
     const uint8_t *subdirs = a.subdirs ? a.subdirs + pair * a.nblocks : nullptr;
     int s2x = 0, s2y = 0, cnt = 0;
-    const int rounds = (a.nblocks + kThreads - 1) / kThreads;  // uniform trip count: ballots need every lane
+    const int rounds = (a.nblocks + GROUP - 1) / GROUP;  // uniform trip count: ballots need every lane
     auto vote = [&](bool ok, aof_block r, int sd) {
         ok = ok && !(r.sad == AOF_SAD_SKIPPED || (int)r.sad >= a.value_threshold);
         int hx = 0, hy = 0;
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
         int sdir[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
-            const int b = (it0 + k) * kThreads + (int)threadIdx.x;
+            const int b = (it0 + k) * GROUP + tid;
             rec[k].dx = 0; rec[k].dy = 0; rec[k].sad = AOF_SAD_SKIPPED;
             sdir[k] = 8;
             if (it0 + k < rounds && b < a.nblocks) {
@@ -99,21 +110,21 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             if (it0 + k >= rounds) break;  // uniform
-            const int b = (it0 + k) * kThreads + (int)threadIdx.x;
+            const int b = (it0 + k) * GROUP + tid;
             vote(b < a.nblocks, rec[k], sdir[k]);
         }
     }
     s2x = (int)wave_sum_u32((uint32_t)s2x);
     s2y = (int)wave_sum_u32((uint32_t)s2y);
     cnt = (int)wave_sum_u32((uint32_t)cnt);
-    if ((threadIdx.x & 63) == 0) {
+    if ((tid & 63) == 0) {
         atomicAdd(&sums[0], s2x);
         atomicAdd(&sums[1], s2y);
         atomicAdd(&sums[2], cnt);
     }
-    __syncthreads();
+    sync();
     }
-    if (threadIdx.x != 0) return;
+    if (tid != 0) return;
     {
 #pragma clang fp contract(off)
     aof_flow out;
@@ -169,8 +180,12 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
 int launch_reduce(const ReduceArgs &a, void *stream)
 {
     if (a.n_pairs == 0) return 0;
-    hipLaunchKernelGGL(k_reduce, dim3((uint32_t)a.n_pairs), dim3(kThreads), 0,
-                       static_cast<hipStream_t>(stream), a);
+    if (a.nblocks <= 256 && !a.parts)  // sparse grids: one wave per pair
+        hipLaunchKernelGGL(k_reduce<64>, dim3((uint32_t)((a.n_pairs + 3) / 4)), dim3(kThreads), 0,
+                           static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(k_reduce<kThreads>, dim3((uint32_t)a.n_pairs), dim3(kThreads), 0,
+                           static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

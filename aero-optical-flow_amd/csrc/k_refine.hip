@@ -33,7 +33,9 @@ __global__ __launch_bounds__(kRefineThreads) void k_refine(SearchArgs a)
     const int blk = blockIdx.x * kRefineThreads + threadIdx.x;
     const int nb = a.grid.blocks();
     if (pair >= a.n_pairs || blk >= nb) return;
-    const aof_block rec = a.blocks[pair * nb + blk];
+    // one dword load (the C ABI requires a 4-byte aligned record array)
+    const aof_block rec = __builtin_bit_cast(
+        aof_block, reinterpret_cast<const uint32_t *>(a.blocks)[pair * nb + blk]);
     uint8_t *out = a.subdirs + pair * nb + blk;
     if (rec.sad == AOF_SAD_SKIPPED || (uint32_t)rec.sad >= (uint32_t)a.value_threshold) {
         *out = 8;
@@ -52,16 +54,33 @@ __global__ __launch_bounds__(kRefineThreads) void k_refine(SearchArgs a)
 #pragma unroll
     for (int r = 0; r < B; r++) __builtin_memcpy(ref[r], pr + r * W, 4 * NW);
 
-    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t pc_[NW], ph_[NW], pl_[NW];  // previous window row: C, H+, H-
-#pragma unroll
-    for (int y = -1; y <= B; y++) {
+    // 8x8: all ten window rows are requested before the first is used (one memory round trip
+    // per block); 16x16 has no registers to spare for that and loads row by row
+    constexpr bool kPreload = NW == 2;
+    uint32_t rows[kPreload ? B + 2 : 1][NW + 1];
+    auto load_row = [&](int y, uint32_t (&d)[NW + 1]) {
         // bytes -1 .. B+1 of the row: NW dwords + one 16-bit tail (never past the ring)
-        uint32_t d[NW + 1];
         uint16_t tail;
         __builtin_memcpy(d, pc + (y + 1) * W, 4 * NW);
         __builtin_memcpy(&tail, pc + (y + 1) * W + 4 * NW, 2);
         d[NW] = tail;
+    };
+    if constexpr (kPreload) {
+#pragma unroll
+        for (int y = -1; y <= B; y++) load_row(y, rows[y + 1]);
+    }
+
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t pc_[NW], ph_[NW], pl_[NW];  // previous window row: C, H+, H-
+#pragma unroll
+    for (int y = -1; y <= B; y++) {
+        uint32_t d[NW + 1];
+        if constexpr (kPreload) {
+#pragma unroll
+            for (int q = 0; q <= NW; q++) d[q] = rows[y + 1][q];
+        } else {
+            load_row(y, d);
+        }
         if (delta != 0) {  // uniform over the workgroup (one pair)
 #pragma unroll
             for (int q = 0; q <= NW; q++) d[q] = sat_add_u8x4(d[q], delta);

@@ -417,7 +417,9 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     // the strip's records are contiguous: (by0 + brow)*nx + bx == by0*nx + blk; keep the
     // 64-bit part of the address wave-uniform (SALU) and the lane part 32-bit
     aof_block *strip_out = a.blocks + (pair * (int64_t)(nx * ny) + (int64_t)by0 * nx);
-    if (writer) strip_out[(uint32_t)blk] = rec;
+    // one dword store per record (aof_block alone is only 2-byte aligned; tile8_supported()
+    // checks the array)
+    if (writer) reinterpret_cast<uint32_t *>(strip_out)[(uint32_t)blk] = __builtin_bit_cast(uint32_t, rec);
 
     // Votes of this strip's accepted blocks, so that K3 sums nstrips small histograms per
     // pair instead of re-reading every record (DESIGN.md "Kernels": K3).
@@ -443,6 +445,7 @@ bool tile8_supported(const SearchArgs &a)
     if (a.grid.x0 != 4 + org || a.grid.y0 != 4 + org || a.grid.step_x != 8 || a.grid.step_y != 8) return false;
     if (a.w % 16 || a.pair_stride % 16) return false;
     if (reinterpret_cast<uintptr_t>(a.prev) % 16 || reinterpret_cast<uintptr_t>(a.cur) % 16) return false;
+    if (reinterpret_cast<uintptr_t>(a.blocks) % 4) return false;
     if ((int64_t)a.w * a.h > 0x7FFFFFFF) return false;
     return plan_tile8(a.w, a.grid.nx, a.grid.ny).rb > 0;
 }

@@ -37,6 +37,8 @@ WORKLOADS = {
            640, 480, dict(pyramid_levels=2, mean_subtract=1), 9),
     "c2h": ("C2 geometry with half-pixel refinement on the dense grid (origin 5, 4582 blocks/pair)",
             640, 480, dict(subpixel=1), 4),
+    "c1b": ("C1 geometry in batch: 64x64, published sparse 5x5 grid, half-pixel refinement",
+            64, 64, dict(_px4flow=1), 4),
     "c5": ("C5 1280x960 pairs, 16x16 SAD, +-8 search",
            1280, 960, dict(tile=16, search=8, value_threshold=12000), 8),
     "c5h": ("C5 geometry with half-pixel refinement (origin 9)",
@@ -254,7 +256,8 @@ def main():
     desc, W, H, over, reach = WORKLOADS[args.workload]
     if args.max_shift is not None:
         reach = args.max_shift
-    p = aof.default_params(W, H, **over)
+    over = dict(over)
+    p = aof.px4flow_params(W, H, **over) if over.pop("_px4flow", 0) else aof.default_params(W, H, **over)
     eng = aof.FlowEngine(p, dev_index)
     if args.search == "pruned":
         eng.set_search_mode(aof.SEARCH_PRUNED)
@@ -357,8 +360,7 @@ def main():
             traffic = None
 
     out = {
-        "metric": "frame-pairs/s (640x480, 8x8 SAD, +-4 search)" if not args.workload.startswith("c5")
-                  else "frame-pairs/s (1280x960, 16x16 SAD, +-8 search)",
+        "metric": f"frame-pairs/s ({W}x{H}, {p.tile}x{p.tile} SAD, +-{p.search} search)",
         "value": round(world * n * args.steps / elapsed, 1),
         "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -140,7 +140,7 @@ int aof_set_search_mode(aof_ctx *ctx, int mode);
  * d_prev/d_cur: device pointers, pair i at +i*pair_stride bytes, each frame
  * width*height bytes.  For a frame SEQUENCE pass d_cur = d_prev + width*height
  * and pair_stride = width*height.
- * d_blocks: [n_pairs][nb0] records or NULL.  d_subdirs: [n_pairs][nb0] or NULL.
+ * d_blocks: [n_pairs][nb0] records (4-byte aligned) or NULL.  d_subdirs: [n_pairs][nb0] or NULL.
  * d_flows: [n_pairs], required.  d_workspace: >= aof_workspace_layout().total_bytes,
  * 256-byte aligned.  stream: hipStream_t (NULL = default stream).
  * Asynchronous: returns after enqueueing; no allocation, no host sync. */

@@ -48,16 +48,18 @@ def test_c1_64x64_px4flow_grid(aof, orc, synth, gpu_device):
     prevs, curs, shifts = synth.make_batch(64, 64, 12, 4, 0, noise=2)
     for i, half in enumerate([(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1), (1, -1), (-1, 1)]):
         prevs[i], curs[i], _ = synth.make_pair(64, 64, 4, i, shift=(1 - i % 3, i % 2), half=half)
-    eng = aof.FlowEngine(p, 0)
-    assert eng.variant == "generic"
     tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
-    sub = torch.empty((12, 25), dtype=torch.uint8, device=gpu_device)
-    blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
-    torch.cuda.synchronize()
-    got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
-    check_against_oracle(aof, orc, p, prevs, curs, got, subdirs=sub.cpu().numpy())
-    seen = set(np.unique(sub.cpu().numpy()[:8]))
-    assert seen >= {0, 1, 2, 3, 4, 5, 6, 7}, f"half-pixel shifted pairs must exercise every direction: {seen}"
+    for generic in (False, True):   # lane-per-block kernel + refinement pass, then the generic kernel
+        eng = aof.FlowEngine(p, 0)
+        assert eng.variant == "lane8"
+        eng.force_generic(generic)
+        sub = torch.full((12, 25), 99, dtype=torch.uint8, device=gpu_device)
+        blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+        torch.cuda.synchronize()
+        got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
+        check_against_oracle(aof, orc, p, prevs, curs, got, subdirs=sub.cpu().numpy())
+        seen = set(np.unique(sub.cpu().numpy()[:8]))
+        assert seen >= {0, 1, 2, 3, 4, 5, 6, 7}, f"half-pixel shifted pairs must exercise every direction: {seen}"
 
 
 def test_c1_64x64_dense(aof, orc, synth, gpu_device):
@@ -165,7 +167,9 @@ def test_c4_batch_properties_at_full_size(aof, orc, synth, gpu_device):
 
 SHAPES = [
     dict(width=128, height=96),                                   # tile8 fast path, several strips
-    dict(width=136, height=72),                                   # width % 16 != 0 -> generic
+    dict(width=136, height=72),                                   # width % 16 != 0 -> lane8
+    dict(width=188, height=120, pyramid_levels=2, mean_subtract=1),  # lane8 with predictor + equalisation
+    dict(width=188, height=120, subpixel=1),                      # lane8 + refine pass
     dict(width=96, height=81),                                    # odd height, 1 level
     dict(width=160, height=128, pyramid_levels=2),                # shifted tile8 path
     dict(width=160, height=128, pyramid_levels=2, mean_subtract=1, hist_filter=0),
