@@ -357,10 +357,11 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         {
             ReduceArgs r;
             r.parts = parts; r.nstrips = nstrips;
-            r.blocks = blocks1; r.subdirs = subdirs1; r.nblocks = ctx->g1.blocks();
-            r.range = level_range(p, 1); r.value_threshold = value_threshold_u16(p);
-            r.hist_filter = p.hist_filter; r.min_valid = p.min_valid;
-            r.flows = flows1; r.pred = nullptr; r.emit_predictor = 1; r.n_pairs = n_pairs;
+            r.blocks = blocks1; r.subdirs = subdirs1;
+            r.value_threshold = value_threshold_u16(p);
+            r.tail.nblocks = ctx->g1.blocks(); r.tail.range = level_range(p, 1);
+            r.tail.hist_filter = p.hist_filter; r.tail.min_valid = p.min_valid;
+            r.tail.flows = flows1; r.tail.pred = nullptr; r.tail.emit_predictor = 1; r.n_pairs = n_pairs;
             Timed t(ctx, AOF_K_REDUCE_L1, s);
             rc = launch_reduce(r, s);
             if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));
@@ -377,10 +378,11 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
     {
         ReduceArgs r;
         r.parts = parts; r.nstrips = nstrips;
-        r.blocks = blocks0; r.subdirs = subdirs0; r.nblocks = ctx->g0.blocks();
-        r.range = level_range(p, 0); r.value_threshold = value_threshold_u16(p);
-        r.hist_filter = p.hist_filter; r.min_valid = p.min_valid;
-        r.flows = d_flows; r.pred = pred; r.emit_predictor = 0; r.n_pairs = n_pairs;
+        r.blocks = blocks0; r.subdirs = subdirs0;
+        r.value_threshold = value_threshold_u16(p);
+        r.tail.nblocks = ctx->g0.blocks(); r.tail.range = level_range(p, 0);
+        r.tail.hist_filter = p.hist_filter; r.tail.min_valid = p.min_valid;
+        r.tail.flows = d_flows; r.tail.pred = pred; r.tail.emit_predictor = 0; r.n_pairs = n_pairs;
         Timed t(ctx, AOF_K_REDUCE, s);
         rc = launch_reduce(r, s);
         if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));

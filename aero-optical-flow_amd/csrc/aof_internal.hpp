@@ -33,6 +33,17 @@ int grid_for_level(const aof_params &p, int level, Grid *g);
 int level_range(const aof_params &p, int level);  // histogram half-range R
 int value_threshold_u16(const aof_params &p);     // SAD gate clamped to the u16 record
 
+// What turns a pair's vote histograms into its aof_flow (K3).
+struct FlowTail {
+    int32_t nblocks;
+    int32_t range;             // R
+    int32_t hist_filter;
+    int32_t min_valid;
+    aof_flow *flows;           // [n_pairs]
+    const aof_flow *pred;      // copy pred_x/pred_y + PRED_VALID from here (level 0 of two), or nullptr
+    int32_t emit_predictor;    // level 1: write the integer predictor into pred_x/pred_y
+};
+
 // Everything one search launch needs; passed to the kernels by value.
 struct SearchArgs {
     const uint8_t *prev;       // level frames of the older image, pair i at +i*stride
@@ -58,14 +69,8 @@ struct SearchArgs {
 struct ReduceArgs {
     const aof_block *blocks;
     const uint8_t *subdirs;    // nullptr when half-pixel refinement is off
-    int32_t nblocks;
-    int32_t range;             // R
     int32_t value_threshold;
-    int32_t hist_filter;
-    int32_t min_valid;
-    aof_flow *flows;           // [n_pairs]
-    const aof_flow *pred;      // copy pred_x/pred_y + PRED_VALID from here (level 0 of two), or nullptr
-    int32_t emit_predictor;    // level 1: write the integer predictor into pred_x/pred_y
+    FlowTail tail;
     int64_t n_pairs;
     const uint32_t *parts;     // per-strip histograms written by the tile8 search (then blocks are not read)
     int32_t nstrips;

@@ -1,0 +1,82 @@
+// Flow finalisation kept apart from K3's vote collection (k_reduce): from the two
+// half-pixel vote histograms of one pair to its 16-byte aof_flow (DESIGN.md "Spec": Reduce).
+// Executed by ONE thread.  The float arithmetic is a handful of exactly-representable integers
+// and correctly-rounded divisions (__fdiv_rn), bit-identical to the host arithmetic of the oracle.
+#pragma once
+
+#include "aof_device.hpp"
+#include "aof_internal.hpp"
+
+namespace aof {
+
+__device__ __forceinline__ void peak_window(int pos, int n, int *lo, int *hi)
+{
+    *lo = *hi = pos;
+    if (pos > 1 && pos < n - 2) { *lo = pos - 2; *hi = pos + 2; }
+    else if (pos == 0) { *hi = pos + 2; }
+    else if (pos == n - 1) { *lo = pos - 2; }
+    else if (pos == 1) { *lo = pos - 1; *hi = pos + 2; }
+    else if (pos == n - 2) { *lo = pos - 2; *hi = pos + 1; }
+}
+
+__device__ __forceinline__ long long floor_div(long long a, long long b)
+{
+    long long q = a / b;
+    if ((a % b) < 0) q--;
+    return q;
+}
+
+// hist_x/hist_y: n = 2*(2R+1)+1 bins each; sums = {sum of 2*dx votes, sum of 2*dy votes, count}.
+__device__ __forceinline__ void finalise_flow(const FlowTail &a, int64_t pair, const uint32_t *hist_x,
+                                              const uint32_t *hist_y, const int *sums)
+{
+#pragma clang fp contract(off)
+    const int centre = 2 * a.range + 1, n = 2 * centre + 1;
+    aof_flow out;
+    out.flow_x = out.flow_y = 0.0f;
+    out.count = (uint32_t)sums[2];
+    out.quality = 0;
+    out.flags = 0;
+    out.pred_x = out.pred_y = 0;
+    int px = 0, py = 0;
+    const long long count = sums[2];
+    if (count > (long long)a.min_valid && count > 0) {
+        if (a.hist_filter) {
+            int posx = 0, posy = 0;
+            uint32_t maxx = 0, maxy = 0;
+            for (int k = 0; k < n; k++) {
+                if (hist_x[k] > maxx) { maxx = hist_x[k]; posx = k; }
+                if (hist_y[k] > maxy) { maxy = hist_y[k]; posy = k; }
+            }
+            int lo, hi;
+            uint32_t vx = 0, wx = 0, vy = 0, wy = 0;
+            peak_window(posx, n, &lo, &hi);
+            for (int k = lo; k <= hi; k++) { vx += (uint32_t)k * hist_x[k]; wx += hist_x[k]; }
+            peak_window(posy, n, &lo, &hi);
+            for (int k = lo; k <= hi; k++) { vy += (uint32_t)k * hist_y[k]; wy += hist_y[k]; }
+            out.flow_x = (__fdiv_rn((float)vx, (float)wx) - (float)centre) / 2.0f;
+            out.flow_y = (__fdiv_rn((float)vy, (float)wy) - (float)centre) / 2.0f;
+            px = (int)(floor_div(2ll * vx + wx, 2ll * wx) - centre);
+            py = (int)(floor_div(2ll * vy + wy, 2ll * wy) - centre);
+        } else {
+            out.flow_x = __fdiv_rn((float)sums[0] * 0.5f, (float)count);
+            out.flow_y = __fdiv_rn((float)sums[1] * 0.5f, (float)count);
+            px = (int)floor_div(2ll * sums[0] + count, 2ll * count);
+            py = (int)floor_div(2ll * sums[1] + count, 2ll * count);
+        }
+        out.quality = (uint8_t)((unsigned long long)count * 255ull / (unsigned long long)a.nblocks);
+        out.flags |= AOF_FLAG_FLOW_VALID;
+    }
+    if (a.emit_predictor) {
+        out.pred_x = (int8_t)px;
+        out.pred_y = (int8_t)py;
+    } else if (a.pred) {
+        const aof_flow p = a.pred[pair];
+        out.pred_x = p.pred_x;
+        out.pred_y = p.pred_y;
+        if (p.flags & AOF_FLAG_FLOW_VALID) out.flags |= AOF_FLAG_PRED_VALID;
+    }
+    a.flows[pair] = out;
+}
+
+}  // namespace aof

@@ -13,6 +13,7 @@
 // (__fdiv_rn), so it is bit-identical to the host arithmetic of the oracle.
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
+#include "aof_reduce.hpp"
 
 namespace aof {
 
@@ -21,23 +22,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxHist = 256;
 constexpr int kBatch = 10;  // record loads in flight per lane
-
-__device__ __forceinline__ void peak_window(int pos, int n, int *lo, int *hi)
-{
-    *lo = *hi = pos;
-    if (pos > 1 && pos < n - 2) { *lo = pos - 2; *hi = pos + 2; }
-    else if (pos == 0) { *hi = pos + 2; }
-    else if (pos == n - 1) { *lo = pos - 2; }
-    else if (pos == 1) { *lo = pos - 1; *hi = pos + 2; }
-    else if (pos == n - 2) { *lo = pos - 2; *hi = pos + 1; }
-}
-
-__device__ __forceinline__ long long floor_div(long long a, long long b)
-{
-    long long q = a / b;
-    if ((a % b) < 0) q--;
-    return q;
-}
 
 // GROUP = threads per pair: 256 (one workgroup per pair) or 64 (one wave per pair, four pairs
 // per workgroup: sparse grids with a few dozen blocks per pair, where a whole workgroup per
@@ -55,7 +39,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
     auto sync = [] { if (GROUP == kThreads) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     uint32_t (*hist)[kMaxHist] = s_hist[grp];
     int *sums = s_sums[grp];
-    const int centre = 2 * a.range + 1, n = 2 * centre + 1;
+    const int centre = 2 * a.tail.range + 1, n = 2 * centre + 1;
     for (int k = tid; k < n; k += GROUP) { hist[0][k] = 0; hist[1][k] = 0; }
     if (tid < 3) sums[tid] = 0;
     sync();
@@ -76,10 +60,10 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
         }
         sync();
     } else {
-    const aof_block *blocks = a.blocks + pair * a.nblocks;
-    const uint8_t *subdirs = a.subdirs ? a.subdirs + pair * a.nblocks : nullptr;
+    const aof_block *blocks = a.blocks + pair * a.tail.nblocks;
+    const uint8_t *subdirs = a.subdirs ? a.subdirs + pair * a.tail.nblocks : nullptr;
     int s2x = 0, s2y = 0, cnt = 0;
-    const int rounds = (a.nblocks + GROUP - 1) / GROUP;  // uniform trip count: ballots need every lane
+    const int rounds = (a.tail.nblocks + GROUP - 1) / GROUP;  // uniform trip count: ballots need every lane
     auto vote = [&](bool ok, aof_block r, int sd) {
         ok = ok && !(r.sad == AOF_SAD_SKIPPED || (int)r.sad >= a.value_threshold);
         int hx = 0, hy = 0;
@@ -102,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
             const int b = (it0 + k) * GROUP + tid;
             rec[k].dx = 0; rec[k].dy = 0; rec[k].sad = AOF_SAD_SKIPPED;
             sdir[k] = 8;
-            if (it0 + k < rounds && b < a.nblocks) {
+            if (it0 + k < rounds && b < a.tail.nblocks) {
                 rec[k] = blocks[b];
                 if (subdirs) sdir[k] = subdirs[b];
             }
@@ -111,7 +95,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
         for (int k = 0; k < kBatch; k++) {
             if (it0 + k >= rounds) break;  // uniform
             const int b = (it0 + k) * GROUP + tid;
-            vote(b < a.nblocks, rec[k], sdir[k]);
+            vote(b < a.tail.nblocks, rec[k], sdir[k]);
         }
     }
     s2x = (int)wave_sum_u32((uint32_t)s2x);
@@ -124,55 +108,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
     }
     sync();
     }
-    if (tid != 0) return;
-    {
-#pragma clang fp contract(off)
-    aof_flow out;
-    out.flow_x = out.flow_y = 0.0f;
-    out.count = (uint32_t)sums[2];
-    out.quality = 0;
-    out.flags = 0;
-    out.pred_x = out.pred_y = 0;
-    int px = 0, py = 0;
-    const long long count = sums[2];
-    if (count > (long long)a.min_valid && count > 0) {
-        if (a.hist_filter) {
-            int posx = 0, posy = 0;
-            uint32_t maxx = 0, maxy = 0;
-            for (int k = 0; k < n; k++) {
-                if (hist[0][k] > maxx) { maxx = hist[0][k]; posx = k; }
-                if (hist[1][k] > maxy) { maxy = hist[1][k]; posy = k; }
-            }
-            int lo, hi;
-            uint32_t vx = 0, wx = 0, vy = 0, wy = 0;
-            peak_window(posx, n, &lo, &hi);
-            for (int k = lo; k <= hi; k++) { vx += (uint32_t)k * hist[0][k]; wx += hist[0][k]; }
-            peak_window(posy, n, &lo, &hi);
-            for (int k = lo; k <= hi; k++) { vy += (uint32_t)k * hist[1][k]; wy += hist[1][k]; }
-            out.flow_x = (__fdiv_rn((float)vx, (float)wx) - (float)centre) / 2.0f;
-            out.flow_y = (__fdiv_rn((float)vy, (float)wy) - (float)centre) / 2.0f;
-            px = (int)(floor_div(2ll * vx + wx, 2ll * wx) - centre);
-            py = (int)(floor_div(2ll * vy + wy, 2ll * wy) - centre);
-        } else {
-            out.flow_x = __fdiv_rn((float)sums[0] * 0.5f, (float)count);
-            out.flow_y = __fdiv_rn((float)sums[1] * 0.5f, (float)count);
-            px = (int)floor_div(2ll * sums[0] + count, 2ll * count);
-            py = (int)floor_div(2ll * sums[1] + count, 2ll * count);
-        }
-        out.quality = (uint8_t)((unsigned long long)count * 255ull / (unsigned long long)a.nblocks);
-        out.flags |= AOF_FLAG_FLOW_VALID;
-    }
-    if (a.emit_predictor) {
-        out.pred_x = (int8_t)px;
-        out.pred_y = (int8_t)py;
-    } else if (a.pred) {
-        const aof_flow p = a.pred[pair];
-        out.pred_x = p.pred_x;
-        out.pred_y = p.pred_y;
-        if (p.flags & AOF_FLAG_FLOW_VALID) out.flags |= AOF_FLAG_PRED_VALID;
-    }
-    a.flows[pair] = out;
-    }
+    if (tid == 0) finalise_flow(a.tail, pair, hist[0], hist[1], sums);
 }
 
 }  // namespace
@@ -180,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
 int launch_reduce(const ReduceArgs &a, void *stream)
 {
     if (a.n_pairs == 0) return 0;
-    if (a.nblocks <= 256 && !a.parts)  // sparse grids: one wave per pair
+    if (a.tail.nblocks <= 256 && !a.parts)  // sparse grids: one wave per pair
         hipLaunchKernelGGL(k_reduce<64>, dim3((uint32_t)((a.n_pairs + 3) / 4)), dim3(kThreads), 0,
                            static_cast<hipStream_t>(stream), a);
     else

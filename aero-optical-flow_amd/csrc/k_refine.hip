@@ -18,6 +18,7 @@
 // eight SADs.  Blocks the search skipped or rejected get direction 8 (none).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
+#include "aof_refine.hpp"
 
 namespace aof {
 
@@ -26,13 +27,15 @@ namespace {
 constexpr int kRefineThreads = 256;
 
 template <int NW>  // dwords per tile row: 2 (8x8) or 4 (16x16)
-__global__ __launch_bounds__(kRefineThreads) void k_refine(SearchArgs a)
+__global__ __launch_bounds__(kRefineThreads) void k_refine(SearchArgs a, int64_t items)
 {
     constexpr int B = 4 * NW;
-    const int64_t pair = blockIdx.y + (int64_t)blockIdx.z * gridDim.y;
-    const int blk = blockIdx.x * kRefineThreads + threadIdx.x;
+    // consecutive lanes = consecutive (pair, block) items: full waves on sparse grids too
+    const int64_t item = (int64_t)blockIdx.x * kRefineThreads + threadIdx.x;
+    if (item >= items) return;
     const int nb = a.grid.blocks();
-    if (pair >= a.n_pairs || blk >= nb) return;
+    const int64_t pair = item / nb;
+    const int blk = (int)(item - pair * nb);
     // one dword load (the C ABI requires a 4-byte aligned record array)
     const aof_block rec = __builtin_bit_cast(
         aof_block, reinterpret_cast<const uint32_t *>(a.blocks)[pair * nb + blk]);
@@ -70,59 +73,24 @@ __global__ __launch_bounds__(kRefineThreads) void k_refine(SearchArgs a)
         for (int y = -1; y <= B; y++) load_row(y, rows[y + 1]);
     }
 
-    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t pc_[NW], ph_[NW], pl_[NW];  // previous window row: C, H+, H-
-#pragma unroll
-    for (int y = -1; y <= B; y++) {
+    RefineState<NW> st;
+    st.init();
+    for_rows<-1, B>([&](auto yc) {
+        constexpr int Y = decltype(yc)::value;
         uint32_t d[NW + 1];
         if constexpr (kPreload) {
 #pragma unroll
-            for (int q = 0; q <= NW; q++) d[q] = rows[y + 1][q];
+            for (int q = 0; q <= NW; q++) d[q] = rows[Y + 1][q];
         } else {
-            load_row(y, d);
+            load_row(Y, d);
         }
-        if (delta != 0) {  // uniform over the workgroup (one pair)
+        if (delta != 0) {
 #pragma unroll
             for (int q = 0; q <= NW; q++) d[q] = sat_add_u8x4(d[q], delta);
         }
-        uint32_t c[NW], hp[NW], hm[NW];
-#pragma unroll
-        for (int q = 0; q < NW; q++) {
-            c[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
-            const uint32_t right = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
-            hp[q] = __builtin_amdgcn_lerp(c[q], right, 0u);
-            hm[q] = __builtin_amdgcn_lerp(c[q], d[q], 0u);
-        }
-#pragma unroll
-        for (int q = 0; q < NW; q++) {
-            if (y >= 0 && y < B) {
-                acc[0] = __builtin_amdgcn_sad_u8(hp[q], ref[y < B ? (y >= 0 ? y : 0) : 0][q], acc[0]);
-                acc[4] = __builtin_amdgcn_sad_u8(hm[q], ref[y < B ? (y >= 0 ? y : 0) : 0][q], acc[4]);
-            }
-            if (y >= 0) {
-                const uint32_t v = __builtin_amdgcn_lerp(pc_[q], c[q], 0u);
-                const uint32_t dr = __builtin_amdgcn_lerp(ph_[q], hp[q], 0u);
-                const uint32_t dl = __builtin_amdgcn_lerp(pl_[q], hm[q], 0u);
-                if (y >= 1) {  // tile row y-1 looks down
-                    acc[2] = __builtin_amdgcn_sad_u8(v, ref[y >= 1 ? y - 1 : 0][q], acc[2]);
-                    acc[1] = __builtin_amdgcn_sad_u8(dr, ref[y >= 1 ? y - 1 : 0][q], acc[1]);
-                    acc[3] = __builtin_amdgcn_sad_u8(dl, ref[y >= 1 ? y - 1 : 0][q], acc[3]);
-                }
-                if (y < B) {   // tile row y looks up
-                    acc[6] = __builtin_amdgcn_sad_u8(v, ref[y < B ? y : 0][q], acc[6]);
-                    acc[7] = __builtin_amdgcn_sad_u8(dr, ref[y < B ? y : 0][q], acc[7]);
-                    acc[5] = __builtin_amdgcn_sad_u8(dl, ref[y < B ? y : 0][q], acc[5]);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NW; q++) { pc_[q] = c[q]; ph_[q] = hp[q]; pl_[q] = hm[q]; }
-    }
-    uint32_t mind = rec.sad;
-    int subdir = 8;
-#pragma unroll
-    for (int dir = 0; dir < 8; dir++)
-        if (acc[dir] < mind) { mind = acc[dir]; subdir = dir; }
+        st.template row<Y>(d, ref);
+    });
+    const int subdir = st.direction(rec.sad);
     *out = (uint8_t)subdir;
 }
 
@@ -131,13 +99,14 @@ __global__ __launch_bounds__(kRefineThreads) void k_refine(SearchArgs a)
 int launch_refine(const SearchArgs &a, void *stream)
 {
     if (a.n_pairs == 0 || !a.subdirs) return 0;
-    const int64_t gy = a.n_pairs < 32768 ? a.n_pairs : 32768;
-    const int64_t gz = (a.n_pairs + gy - 1) / gy;
-    const dim3 grid((uint32_t)((a.grid.blocks() + kRefineThreads - 1) / kRefineThreads), (uint32_t)gy, (uint32_t)gz);
+    const int64_t items = a.n_pairs * a.grid.blocks();
+    const int64_t wgs = (items + kRefineThreads - 1) / kRefineThreads;
+    if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
+    const dim3 grid((uint32_t)wgs);
     if (a.tile == 8)
-        hipLaunchKernelGGL(k_refine<2>, grid, dim3(kRefineThreads), 0, static_cast<hipStream_t>(stream), a);
+        hipLaunchKernelGGL(k_refine<2>, grid, dim3(kRefineThreads), 0, static_cast<hipStream_t>(stream), a, items);
     else if (a.tile == 16)
-        hipLaunchKernelGGL(k_refine<4>, grid, dim3(kRefineThreads), 0, static_cast<hipStream_t>(stream), a);
+        hipLaunchKernelGGL(k_refine<4>, grid, dim3(kRefineThreads), 0, static_cast<hipStream_t>(stream), a, items);
     else
         return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();

@@ -239,6 +239,43 @@ def test_vga_dense_half_pixel(aof, orc, synth, gpu_device, mode, kw):
     assert seen >= {0, 1, 2, 3, 4, 5, 6, 7}, seen
 
 
+SMALL = [
+    (dict(px4=1), 64, 64),                                      # configs[0]
+    (dict(px4=1, mean_subtract=1, hist_filter=0), 64, 64),
+    (dict(px4=1, num_blocks=8), 96, 80),
+    (dict(subpixel=1), 128, 128),                               # the reference application's image size, dense
+    (dict(subpixel=1, mean_subtract=1), 128, 96),
+    (dict(), 136, 72),                                          # rows of 136 bytes: no strip kernel
+    (dict(mean_subtract=1, feature_threshold=0, value_threshold=70000), 100, 64),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SMALL)))
+def test_small_frames(aof, orc, synth, gpu_device, case):
+    """Small frames (the reference's own sizes) on sparse and dense grids: lane-per-block search,
+    refinement pass and wave-per-pair reduction against the oracle; every half-pixel direction."""
+    import torch
+    kw, w, h = SMALL[case]
+    kw = dict(kw)
+    p = aof.px4flow_params(w, h, **kw) if kw.pop("px4", 0) else aof.default_params(w, h, **kw)
+    n = 23
+    prevs, curs, _ = synth.make_batch(w, h, n, 4, 6100 + case, noise=3, brightness=9 if p.mean_subtract else 0)
+    for i, half in enumerate([(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1), (1, -1), (-1, 1)]):
+        prevs[i], curs[i], _ = synth.make_pair(w, h, 4, 70 + i, shift=(2 - i % 5, i % 3 - 1), half=half)
+    rng = np.random.default_rng(case)
+    curs[n - 1] = rng.integers(0, 256, curs[n - 1].shape, dtype=np.uint8)
+    prevs[n - 2][: h // 2] = 90
+    eng = aof.FlowEngine(p, 0)
+    tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
+    sub = torch.full((n, eng.nblocks(0)), 99, dtype=torch.uint8, device=gpu_device) if p.subpixel else None
+    blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+    torch.cuda.synchronize()
+    got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
+    check_against_oracle(aof, orc, p, prevs, curs, got, subdirs=sub.cpu().numpy() if sub is not None else None)
+    if p.subpixel:
+        assert set(np.unique(sub.cpu().numpy()[:8])) >= {0, 1, 2, 3, 4, 5, 6, 7}
+
+
 def test_flat_and_saturated_frames(aof, orc, gpu_device):
     p = aof.default_params(128, 96)
     prevs = np.stack([np.full((96, 128), v, np.uint8) for v in (0, 77, 255)])
