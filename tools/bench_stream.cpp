@@ -12,17 +12,19 @@ int main(int argc, char **argv)
     aof_params_px4flow(&p, w, h, 4, 30, 3000);
     std::vector<uint8_t> f[2];
     for (int k = 0; k < 2; k++) { f[k].resize((size_t)w * h); for (auto &v : f[k]) v = rand() & 255; }
-    for (int graph = 1; graph >= 0; graph--) {
+    for (int mode = 0; mode < 4; mode++) {
+        const int graph = !(mode & 1), generic = mode >> 1;
         aof_ctx *ctx;
         if (aof_create(&p, 0, &ctx)) { printf("no device\n"); return 1; }
+        aof_set_force_generic(ctx, generic);
         aof_set_stream_graph(ctx, graph);
         aof_flow out;
         for (int i = 0; i < 50; i++) aof_stream_push_host(ctx, f[i & 1].data(), &out);
         auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < calls; i++) aof_stream_push_host(ctx, f[i & 1].data(), &out);
         double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
-        printf("%dx%d graph=%d instantiated=%d: %.2f us per call (quality %d)\n", w, h, graph,
-               aof_set_stream_graph(ctx, -1), us, out.quality);
+        printf("%dx%d %s graph=%d instantiated=%d: %.2f us per call (quality %d)\n", w, h,
+               aof_search_variant(ctx), graph, aof_set_stream_graph(ctx, -1), us, out.quality);
         aof_destroy(ctx);
     }
     return 0;

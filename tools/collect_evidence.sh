@@ -1,0 +1,27 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): bench lines, rocprofv3 kernel-trace stats and the
+# HBM-traffic PMC passes for the bench workloads, all under gpurun_out/evidence/.
+# rocprofv3 gets the program itself after "--" and --pmc is never combined with other traces
+# than --kernel-trace.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/evidence
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for wl in c2 c3 c5 c2h c1b; do
+    extra=""; [ $wl = c5 ] && extra="--pairs 256"; [ $wl = c1b ] && extra="--pairs 65536"
+    timeout -k 10 300 python3 $R/bench.py --workload $wl $extra --steps 50 --warmup 5 > $O/bench_$wl.json 2> $O/bench_$wl.err || { echo "bench $wl failed"; exit 1; }
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$wl -- python3 $R/bench.py --workload $wl $extra --steps 20 --warmup 3 --cpu-seconds 0 > $O/kt_$wl.log 2>&1 || { echo "kernel trace $wl failed"; exit 1; }
+    python3 $R/tools/summarize_rocprof.py $(ls $O/kt_$wl/*/*kernel_stats.csv | head -1) "bench.py --workload $wl $extra --steps 20 --warmup 3" > $O/kernel_stats_$wl.txt
+    rm -rf $O/kt_$wl
+    echo "$wl done"
+done
+for wl in c2 c3; do
+    for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"; do
+        tag=$(echo $set | cut -d" " -f1)
+        timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$wl/$tag -- python3 $R/bench.py --workload $wl --steps 5 --warmup 2 --cpu-seconds 0 > $O/pmc_${wl}_$tag.log 2>&1 || { echo "pmc $wl $tag failed"; exit 1; }
+    done
+    python3 $R/tools/pmc_summary.py $O/pmc_$wl $wl 1024 $O/pmc_$wl.txt > /dev/null
+    rm -rf $O/pmc_$wl
+    echo "pmc $wl done"
+done
