@@ -129,13 +129,10 @@ int run_search(aof_ctx *ctx, SearchArgs a, uint32_t *parts, const uint32_t **par
     *parts_used = nullptr;
     *nstrips = 0;
     if (!ctx->force_generic && tile8_supported(a)) {
-        if (!a.subpixel) {  // votes without half-pixel offsets: K3 can sum the strips' histograms
-            a.hist_parts = parts;
-            *parts_used = parts;
-            *nstrips = plan_tile8(a.w, a.grid.nx, a.grid.ny).nstrips;
-        }
+        a.hist_parts = parts;   // the strips vote (half-pixel offsets included): K3 sums them
+        *parts_used = parts;
+        *nstrips = plan_tile8(a.w, a.grid.nx, a.grid.ny).nstrips;
         rc = launch_search_tile8(a, s);
-        if (!rc && a.subpixel) rc = launch_refine(a, s);  // adds the half-pixel directions
     } else if (!ctx->force_generic && tile16_supported(a)) {
         rc = launch_search_tile16(a, s);
         if (!rc && a.subpixel) rc = launch_refine(a, s);

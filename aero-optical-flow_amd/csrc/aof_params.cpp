@@ -70,7 +70,8 @@ Tile8Plan plan_tile8(int w, int nx, int ny)
         if (g_lab_rb) threads = (items + 63) / 64 * 64;
 #endif
         // cur rows + prev rows + 16 pad, per-block best keys, vote histograms (<= 2*104 bins)
-        const size_t lds = (size_t)(16 * rb + 8) * w + 16 + 4 * (size_t)(rb * nx) + 4 * 2 * 104;
+        // (+ two ring rows and the lead pad of the half-pixel variant)
+        const size_t lds = (size_t)(16 * rb + 8 + 2) * w + 16 + 16 + 4 * (size_t)(rb * nx) + 4 * 2 * 104;
         if (threads > kMaxThreads || lds > kLdsBudget) break;
         const int nstrips = (ny + rb - 1) / rb;
         const double eff = (double)nx * ny * (9 / dyg) / ((double)nstrips * threads);

@@ -26,6 +26,7 @@
 // at the 8-aligned LDS column 8*(bx + (px >> 3)).  The search loop is identical.
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
+#include "aof_refine.hpp"
 
 namespace aof {
 
@@ -91,11 +92,14 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     int start_row = 4;                                // dy index visited first (wave-uniform)
     int prune_pays = 1;                               // previous strip of this wave dropped rows
     for (int strip = first_strip; strip < min(nstrips, first_strip + spw); strip++) {
-    // With half-pixel refinement the grid origin is S+1 = 5: the same geometry as the S = 4
-    // grid on a frame whose origin is moved by (1, 1).  Rows keep the pitch W; windows must
-    // stay inside [0, W-2) x [0, H-2) of the moved frame (one pixel of ring on every side).
+    // With half-pixel refinement the grid origin is S+1 = 5 and every search window carries a
+    // one-pixel ring.  The strip is then staged one byte later per row (LDS column c = frame
+    // column c + 1, so windows stay 8-byte aligned) with one extra row above and below: window
+    // rows start at LDS row 8*brow + 1, the ring at 8*brow.  The ring column left of the first
+    // block is the last byte of the previous LDS row -- the flat copy puts the right pixel there
+    // -- except for the first staged row, whose lead byte is fetched separately.
     const int org = a.grid.x0 - 4;                    // 0, or 1 with the half-pixel margin
-    const int W = a.w, H = a.h - 2 * org, Wb = a.w - 2 * org, nx = a.grid.nx, ny = a.grid.ny;
+    const int W = a.w, H = a.h, Wb = a.w - 2 * org, nx = a.grid.nx, ny = a.grid.ny;
     const int by0 = strip * rb;
     const int rows = min(rb, ny - by0);
     const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -106,24 +110,26 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(a.w * a.h));
 
     // ---- stage the strip into LDS (flat 16-byte copies) ----
-    const int n_cur_rows = 8 * rows + 8;
+    const int n_cur_rows = 8 * rows + 8 + 2 * org;
     const int yc0 = 8 * by0 + py;                 // frame row of LDS cur row 0
     const int r_lo = max(0, -yc0);                // valid LDS cur rows [r_lo, r_hi)
     const int r_hi = min(n_cur_rows, H - yc0);
-    uint8_t *s_cur = smem;
-    uint8_t *s_prev = smem + (8 * rb + 8) * W;
-    uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + (16 * rb + 8) * W + 16);
+    constexpr uint32_t kLead = 16;                // room for the lead byte in front of the cur rows
+    const uint32_t prev_off = kLead + (uint32_t)((8 * rb + 8 + 2 * org) * W);
+    uint8_t *s_cur = smem + kLead;
+    uint8_t *s_prev = smem + prev_off;
+    uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + prev_off + (uint32_t)(8 * rb * W) + 16);
     uint32_t *s_hist = s_best + rb * nx;            // [2][bins] votes of this strip
     const int centre = 2 * a.hist_range + 1, bins = 2 * centre + 1;
     const int sh7 = SHIFTED ? (px & 7) : 0;        // floor-mod: px = 8*(px >> 3) + sh7
-    const int64_t org_off = (int64_t)org * (W + 1);  // moved frame origin, in bytes
-    const uint8_t *g_cur = a.cur + pair * a.pair_stride + org_off + (int64_t)(yc0 + r_lo) * W + sh7;
-    const uint8_t *g_prev = a.prev + pair * a.pair_stride + org_off + (int64_t)(8 * by0 + 4) * W;
+    const uint8_t *g_cur = a.cur + pair * a.pair_stride + org + (int64_t)(yc0 + r_lo) * W + sh7;
+    const uint8_t *g_prev = a.prev + pair * a.pair_stride + (int64_t)org * (W + 1) + (int64_t)(8 * by0 + 4) * W;
     int cur_chunks = r_hi > r_lo ? (r_hi - r_lo) * (W / 16) : 0;
     const int prev_chunks = 8 * rows * (W / 16);
-    // The pre-shifted copy runs sh7 bytes past its last row; when that row is the last
+    // The displaced copy runs sh7 + org bytes past its last row; when that row is the last
     // row of the frame the final chunk is copied bytewise with a bounds check instead.
-    const bool tail_guard = SHIFTED && sh7 != 0 && cur_chunks > 0 && org == 0 && yc0 + r_hi == H;
+    const int over = sh7 + org;
+    const bool tail_guard = over != 0 && cur_chunks > 0 && yc0 + r_hi == H;
     if (tail_guard) cur_chunks -= 1;
     if (LAB_MODE == 1) {
         // lab: no global traffic
@@ -151,9 +157,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
             }
             *reinterpret_cast<uint4 *>(s_cur + r_lo * W + c * 16) = v;
         }
-        if (tail_guard && tid < 16 - sh7)
+        if (tail_guard && tid < 16 - over)
             s_cur[r_lo * W + cur_chunks * 16 + tid] =
                 (uint8_t)clamp_u8((int)g_cur[cur_chunks * 16 + tid] + delta);
+        // lead byte: ring column left of block column 0 in the first staged row
+        if (org != 0 && cur_chunks > 0 && tid == 0)
+            (s_cur + r_lo * W)[-1] = (uint8_t)clamp_u8((int)g_cur[-1] + delta);
     }
     if (LAB_MODE != 1 && org != 0) {  // moved origin: byte-aligned source, through registers
         for (int c = tid; c < prev_chunks; c += nthreads) {
@@ -197,18 +206,17 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     int xs = 8 * bx;                              // LDS byte column of the window start
     if (SHIFTED) {
         const int xf = 8 * bx + px;               // frame column of the window start
-        inside = xf >= 0 && xf + 16 <= Wb && 8 * brow >= r_lo && 8 * brow + 16 <= r_hi;
+        inside = xf >= 0 && xf + 16 <= Wb && 8 * brow >= r_lo && 8 * brow + 16 + 2 * org <= r_hi;
         xs = inside ? xf - sh7 : 0;               // 8-aligned; ignored reads stay in range
     }
 
     uint32_t diff = 0, best = 0xFFFFFFFFu;
+    uint32_t ref[8][2];  // reference tile: 8 rows x 2 dwords (also feeds the half-pixel refinement)
     // whole waves beyond the strip's blocks skip the search (wave-uniform) but still
     // reach the barriers and the vote below
     if ((tid & ~63) < nblk * NG) {
-    // reference tile: 8 rows x 2 dwords, frame column 8*bx + 4
-    uint32_t ref[8][2];
+    // reference tile at frame column 8*bx + 4 (+ org)
     // LDS offsets as 32-bit integers from the one shared array (no 64-bit pointer maths)
-    const uint32_t prev_off = (uint32_t)((8 * rb + 8) * W);
     const uint32_t ref_off = prev_off + (uint32_t)(8 * brow * W + 8 * bx + 4);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
         // better order saved, and workgroups of one pair run concurrently anyway.)
         const bool need = live && inside && diff >= (uint32_t)a.feature_threshold;
         const int start = __builtin_amdgcn_readfirstlane(start_row);
-        const uint32_t win_base = (uint32_t)(8 * brow * W + xs);
+        const uint32_t win_base = kLead + (uint32_t)((8 * brow + org) * W + xs);
         // Only the two rows of the first test (r = 0, 4) are fetched ahead, one dy row early
         // (ping-pong registers), so pruned rows cost two LDS reads; the other six rows are read
         // only when the row survives.  (Fetching all eight ahead made the kernel LDS-bound:
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
 #pragma unroll
     for (int d = 0; d < DYG; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)((s0 + d) * 9 + 8); }
 
-    const uint32_t win_off = (uint32_t)((8 * brow + s0) * W + xs);  // s_cur is at offset 0
+    const uint32_t win_off = kLead + (uint32_t)((8 * brow + org + s0) * W + xs);
 #pragma unroll
     for (int s = 0; s < kRows; s++) {
         const uint2 *p = reinterpret_cast<const uint2 *>(smem + (win_off + (uint32_t)(s * W)));
@@ -420,13 +428,43 @@ __global__ __launch_bounds__(kMaxThreads) void k_search_tile8(SearchArgs a, int 
     // one dword store per record (aof_block alone is only 2-byte aligned; tile8_supported()
     // checks the array)
     if (writer) reinterpret_cast<uint32_t *>(strip_out)[(uint32_t)blk] = __builtin_bit_cast(uint32_t, rec);
+    const bool ok = writer && rec.sad != AOF_SAD_SKIPPED && (int)rec.sad < a.value_threshold;
+
+    // Half-pixel refinement of accepted blocks, from the ring around the best match that the
+    // strip already holds in LDS (equalised): aligned dwords + v_alignbyte by the lane's phase.
+    int hx = 0, hy = 0;
+    if (a.subpixel) {  // uniform
+        int subdir = 8;
+        if (ok) {
+            const int idx = (int)(best & 0xFFFFu);
+            // ring top-left: LDS row 8*brow + dy index, column xs + dx index - 1
+            const int at = (8 * brow + idx / 9) * W + xs + idx % 9 - 1;
+            const uint32_t sh = (uint32_t)(at & 3);
+            const uint32_t base = kLead + (uint32_t)(at & ~3);   // at >= -1: the lead pad covers it
+            RefineState<2> st;
+            st.init();
+            for_rows<-1, 8>([&](auto yc) {
+                constexpr int Y = decltype(yc)::value;
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(smem + (base + (uint32_t)((Y + 1) * W)));
+                uint32_t d[3];
+                d[0] = __builtin_amdgcn_alignbyte(q[1], q[0], sh);
+                d[1] = __builtin_amdgcn_alignbyte(q[2], q[1], sh);
+                d[2] = __builtin_amdgcn_alignbyte(q[3], q[2], sh);
+                st.template row<Y>(d, ref);
+            });
+            subdir = st.direction(rec.sad);
+            hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
+            hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
+        }
+        if (writer && a.subdirs)
+            a.subdirs[pair * (int64_t)(nx * ny) + (int64_t)by0 * nx + blk] = (uint8_t)subdir;
+    }
 
     // Votes of this strip's accepted blocks, so that K3 sums nstrips small histograms per
     // pair instead of re-reading every record (DESIGN.md "Kernels": K3).
     if (a.hist_parts) {
-        const bool ok = writer && rec.sad != AOF_SAD_SKIPPED && (int)rec.sad < a.value_threshold;
-        wave_vote(s_hist, 2 * rec.dx + centre, ok);
-        wave_vote(s_hist + bins, 2 * rec.dy + centre, ok);
+        wave_vote(s_hist, 2 * rec.dx + hx + centre, ok);
+        wave_vote(s_hist + bins, 2 * rec.dy + hy + centre, ok);
         __syncthreads();
         uint32_t *out = a.hist_parts + ((size_t)pair * nstrips + strip) * (size_t)(2 * bins);
         for (int k = tid; k < 2 * bins; k += nthreads) out[k] = s_hist[k];
