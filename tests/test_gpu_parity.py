@@ -177,6 +177,8 @@ SHAPES = [
     dict(width=128, height=96, subpixel=1),                       # dense + half-pixel: tile8 + refine pass
     dict(width=160, height=128, subpixel=1, pyramid_levels=2, mean_subtract=1),
     dict(width=160, height=130, subpixel=1, pyramid_levels=2),    # shifted path, odd level-1 height
+    dict(width=160, height=130, subpixel=1),                      # H = 8k+18: the ring's last row is the frame's last row
+    dict(width=128, height=98, subpixel=1, mean_subtract=1),
     dict(width=128, height=128, grid_mode=1, subpixel=1, num_blocks=7),
     dict(width=128, height=96, grid_mode=1, subpixel=1, pyramid_levels=2, mean_subtract=1),
     dict(width=96, height=96, tile=16, search=8, value_threshold=12000),
