@@ -122,12 +122,14 @@ SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const
 
 // Runs the level's search; *parts_used says whether the kernel wrote per-strip histograms
 // into `parts` (only the tile8 kernel does), in which case K3 sums those instead of the records.
-int run_search(aof_ctx *ctx, SearchArgs a, uint32_t *parts, const uint32_t **parts_used, int *nstrips,
-               hipStream_t s)
+// *reduced: the search kernel also wrote the pairs' flow records (grouped lane8), no K3 follows.
+int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, uint32_t *parts,
+               const uint32_t **parts_used, int *nstrips, bool *reduced, hipStream_t s)
 {
     int rc;
     *parts_used = nullptr;
     *nstrips = 0;
+    *reduced = false;
     if (!ctx->force_generic && tile8_supported(a)) {
         a.hist_parts = parts;   // the strips vote (half-pixel offsets included): K3 sums them
         *parts_used = parts;
@@ -136,9 +138,13 @@ int run_search(aof_ctx *ctx, SearchArgs a, uint32_t *parts, const uint32_t **par
     } else if (!ctx->force_generic && tile16_supported(a)) {
         rc = launch_search_tile16(a, s);
         if (!rc && a.subpixel) rc = launch_refine(a, s);
-    } else if (!ctx->force_generic && lane8_supported(a)) {
-        rc = launch_search_lane8(a, s);
-        if (!rc && a.subpixel) rc = launch_refine(a, s);
+    } else if (!ctx->force_generic && lane8_supported(a)) {  // refines in the same lane
+        if (lane8_group(a) > 0) {
+            rc = launch_flow_lane8(a, tail, s);  // and finalises the flow records
+            *reduced = true;
+        } else {
+            rc = launch_search_lane8(a, s);
+        }
     }
     else rc = launch_search_generic(a, s);
     if (rc) return fail(ctx, -EIO, "search launch: %s", hipGetErrorString((hipError_t)rc));
@@ -339,47 +345,54 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
     const aof_flow *pred = nullptr;
     const uint32_t *parts = nullptr;
     int nstrips = 0;
+    bool reduced = false;
     if (two) {
         aof_block *blocks1 = reinterpret_cast<aof_block *>(ws + L.l1_blocks);
         uint8_t *subdirs1 = p.subpixel ? ws + L.l1_subdirs : nullptr;
         aof_flow *flows1 = reinterpret_cast<aof_flow *>(ws + L.l1_flows);
         const int64_t l1_stride = (int64_t)(p.width / 2) * (p.height / 2);
+        FlowTail tail1;
+        tail1.nblocks = ctx->g1.blocks(); tail1.range = level_range(p, 1);
+        tail1.hist_filter = p.hist_filter; tail1.min_valid = p.min_valid;
+        tail1.flows = flows1; tail1.pred = nullptr; tail1.emit_predictor = 1;
         {
             SearchArgs a = search_args(ctx, 1, ws + L.l1_prev, ws + L.l1_cur, l1_stride, blocks1,
                                        subdirs1, nullptr, sums, n_pairs);
             Timed t(ctx, AOF_K_SEARCH_L1, s);
-            rc = run_search(ctx, a, reinterpret_cast<uint32_t *>(ws + L.l1_hist), &parts, &nstrips, s);
+            rc = run_search(ctx, a, tail1, reinterpret_cast<uint32_t *>(ws + L.l1_hist), &parts, &nstrips,
+                            &reduced, s);
             if (rc) return rc;
         }
-        {
+        if (!reduced) {
             ReduceArgs r;
             r.parts = parts; r.nstrips = nstrips;
             r.blocks = blocks1; r.subdirs = subdirs1;
             r.value_threshold = value_threshold_u16(p);
-            r.tail.nblocks = ctx->g1.blocks(); r.tail.range = level_range(p, 1);
-            r.tail.hist_filter = p.hist_filter; r.tail.min_valid = p.min_valid;
-            r.tail.flows = flows1; r.tail.pred = nullptr; r.tail.emit_predictor = 1; r.n_pairs = n_pairs;
+            r.tail = tail1; r.n_pairs = n_pairs;
             Timed t(ctx, AOF_K_REDUCE_L1, s);
             rc = launch_reduce(r, s);
             if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));
         }
         pred = flows1;
     }
+    FlowTail tail0;
+    tail0.nblocks = ctx->g0.blocks(); tail0.range = level_range(p, 0);
+    tail0.hist_filter = p.hist_filter; tail0.min_valid = p.min_valid;
+    tail0.flows = d_flows; tail0.pred = pred; tail0.emit_predictor = 0;
     {
         SearchArgs a = search_args(ctx, 0, d_prev, d_cur, pair_stride, blocks0, subdirs0, pred, sums,
                                    n_pairs);
         Timed t(ctx, AOF_K_SEARCH, s);
-        rc = run_search(ctx, a, reinterpret_cast<uint32_t *>(ws + L.l0_hist), &parts, &nstrips, s);
+        rc = run_search(ctx, a, tail0, reinterpret_cast<uint32_t *>(ws + L.l0_hist), &parts, &nstrips,
+                        &reduced, s);
         if (rc) return rc;
     }
-    {
+    if (!reduced) {
         ReduceArgs r;
         r.parts = parts; r.nstrips = nstrips;
         r.blocks = blocks0; r.subdirs = subdirs0;
         r.value_threshold = value_threshold_u16(p);
-        r.tail.nblocks = ctx->g0.blocks(); r.tail.range = level_range(p, 0);
-        r.tail.hist_filter = p.hist_filter; r.tail.min_valid = p.min_valid;
-        r.tail.flows = d_flows; r.tail.pred = pred; r.tail.emit_predictor = 0; r.n_pairs = n_pairs;
+        r.tail = tail0; r.n_pairs = n_pairs;
         Timed t(ctx, AOF_K_REDUCE, s);
         rc = launch_reduce(r, s);
         if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));

@@ -97,10 +97,13 @@ int launch_refine(const SearchArgs &a, void *stream);
 bool tile8_supported(const SearchArgs &a);
 int launch_search_tile8(const SearchArgs &a, void *stream);
 // Lane-per-block kernel straight from global memory for B=8, S=4 on ANY grid / width /
-// predictor (sparse PX4Flow grid, rows that are no multiple of 16 bytes).  Integer search only:
-// K2b adds the half-pixel directions.
+// predictor (sparse PX4Flow grid, rows that are no multiple of 16 bytes), half-pixel refinement
+// included.
 bool lane8_supported(const SearchArgs &a);
 int launch_search_lane8(const SearchArgs &a, void *stream);
+// Grids of 8..128 blocks: a workgroup owns whole pairs and also writes their flow records (no K3).
+int lane8_group(const SearchArgs &a);  // pairs per workgroup, 0 = not applicable
+int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream);
 // LDS-tiled (block, dy)-per-lane kernel for B=16, S=8 on a dense grid, no predictor.
 bool tile16_supported(const SearchArgs &a);
 int launch_search_tile16(const SearchArgs &a, void *stream);

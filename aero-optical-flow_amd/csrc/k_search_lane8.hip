@@ -8,10 +8,12 @@
 // loads) straight from global memory -- small frames stay in L2, e.g. a 64x64 pair is 8 KB --
 // and runs the same arithmetic as k_search_tile8: per (search row, reference row) four
 // v_qsad_pk_u16_u8 and two v_sad_hi_u8, packed u16 accumulators, per-lane v_min3 arg-min over
-// (sad << 16 | idx) = first minimum in scan order.  Half-pixel refinement, when enabled, is
-// the separate K2b pass over the records (k_refine.hip).
+// (sad << 16 | idx) = first minimum in scan order.  Half-pixel refinement, when enabled,
+// follows in the same lane from the ring of the best match (aof_refine.hpp).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
+#include "aof_reduce.hpp"
+#include "aof_refine.hpp"
 
 namespace aof {
 
@@ -25,15 +27,11 @@ __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 }
 __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | lo; }
 
-// Two to three waves per SIMD: the kernel trades occupancy for registers, so that a lane has
-// all 24 of its row loads in flight at once (one memory round trip per block instead of 16).
-__global__ __launch_bounds__(kThreads, 2) void k_search_lane8(SearchArgs a, int64_t items)
+// One block: record (and direction) written to global memory and returned for the votes.
+// Returns the half-pixel direction (8 = none).
+__device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, int blk, int64_t item,
+                                            aof_block &rec)
 {
-    const int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (item >= items) return;
-    const int nb = a.grid.blocks();
-    const int64_t pair = item / nb;
-    const int blk = (int)(item - pair * nb);
     const int bx = blk % a.grid.nx, by = blk / a.grid.nx;
     const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y;
     const int W = a.w, m = a.subpixel ? 1 : 0;
@@ -41,14 +39,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_search_lane8(SearchArgs a, int6
     if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(a.w * a.h));
 
-    aof_block rec;
     rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
     uint32_t *out = reinterpret_cast<uint32_t *>(a.blocks) + item;  // one dword store per record
     // the search window (plus the half-pixel ring) must lie inside the frame
     const int wx0 = i + px - 4, wy0 = j + py - 4;
     if (wx0 - m < 0 || wy0 - m < 0 || wx0 + 16 + m > a.w || wy0 + 16 + m > a.h) {
         *out = __builtin_bit_cast(uint32_t, rec);
-        return;
+        if (a.subdirs) a.subdirs[item] = 8;
+        return 8;
     }
     const uint8_t *pr = a.prev + pair * a.pair_stride + (int64_t)j * W + i;
     const uint8_t *pc = a.cur + pair * a.pair_stride + (int64_t)wy0 * W + wx0;
@@ -74,7 +72,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_search_lane8(SearchArgs a, int6
     }
     if (diff < (uint32_t)a.feature_threshold) {
         *out = __builtin_bit_cast(uint32_t, rec);
-        return;
+        if (a.subdirs) a.subdirs[item] = 8;
+        return 8;
     }
 
     // per dy: offsets 0..3 / 4..7 as packed u16, offset 8 as (sad << 16 | idx)
@@ -118,6 +117,86 @@ __global__ __launch_bounds__(kThreads, 2) void k_search_lane8(SearchArgs a, int6
     rec.dy = (int8_t)(py + idx / 9 - 4);
     rec.sad = (uint16_t)(best >> 16);
     *out = __builtin_bit_cast(uint32_t, rec);
+
+    // Half-pixel refinement of accepted blocks: the ring of the best match, rows -1..8 and
+    // bytes -1..8, again straight from global memory (the lines were touched a moment ago).
+    int subdir = 8;
+    if (a.subdirs) {
+        if ((uint32_t)rec.sad < (uint32_t)a.value_threshold) {
+            const uint8_t *ring = pc + (idx / 9 - 1) * W + (idx % 9 - 1);
+            uint32_t rows[10][3];
+#pragma unroll
+            for (int y = 0; y < 10; y++) {
+                uint16_t tail;
+                __builtin_memcpy(rows[y], ring + y * W, 8);
+                __builtin_memcpy(&tail, ring + y * W + 8, 2);
+                rows[y][2] = tail;
+            }
+            RefineState<2> st;
+            st.init();
+            for_rows<-1, 8>([&](auto yc) {
+                constexpr int Y = decltype(yc)::value;
+                uint32_t d[3] = {rows[Y + 1][0], rows[Y + 1][1], rows[Y + 1][2]};
+                if (delta != 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) d[q] = sat_add_u8x4(d[q], delta);
+                }
+                st.template row<Y>(d, ref);
+            });
+            subdir = st.direction(rec.sad);
+        }
+        a.subdirs[item] = (uint8_t)subdir;
+    }
+    return subdir;
+}
+
+// Flat mapping: 256 consecutive (pair, block) items per workgroup; K3 follows.
+// Two to three waves per SIMD: the kernel trades occupancy for registers, so that a lane has
+// all 24 of its row loads in flight at once (one memory round trip per block instead of 16).
+__global__ __launch_bounds__(kThreads, 2) void k_search_lane8(SearchArgs a, int64_t items)
+{
+    const int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (item >= items) return;
+    const int nb = a.grid.blocks();
+    const int64_t pair = item / nb;
+    aof_block rec;
+    (void)search_block(a, pair, (int)(item - pair * nb), item, rec);
+}
+
+// Grouped mapping for grids of a few dozen blocks (the published sparse grid): a workgroup owns
+// `ppw` WHOLE pairs, so their votes meet in LDS and one lane per pair finalises the flow record
+// -- no K3 launch, no second pass over the records.
+__global__ __launch_bounds__(kThreads, 2) void k_flow_lane8(SearchArgs a, FlowTail tail, int ppw)
+{
+    extern __shared__ uint32_t s_votes[];  // [ppw][2][n]
+    const int nb = a.grid.blocks(), tid = threadIdx.x;
+    const int centre = 2 * a.hist_range + 1, n = 2 * centre + 1;
+    const int64_t pair0 = (int64_t)blockIdx.x * ppw;
+    const int np = (int)min((int64_t)ppw, a.n_pairs - pair0);
+    for (int k = tid; k < ppw * 2 * n; k += kThreads) s_votes[k] = 0;
+    __syncthreads();
+    const bool live = tid < np * nb;
+    const int p = live ? tid / nb : 0, blk = live ? tid - p * nb : 0;
+    aof_block rec;
+    rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
+    int subdir = 8;
+    if (live) subdir = search_block(a, pair0 + p, blk, (pair0 + p) * nb + blk, rec);
+    const bool ok = live && (uint32_t)rec.sad < (uint32_t)a.value_threshold;  // skipped = 0xFFFF
+    const int hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
+    const int hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
+    wave_vote(s_votes, p * 2 * n + 2 * rec.dx + hx + centre, ok);
+    wave_vote(s_votes, p * 2 * n + n + 2 * rec.dy + hy + centre, ok);
+    __syncthreads();
+    if (tid < np) {
+        const uint32_t *hxp = s_votes + tid * 2 * n, *hyp = hxp + n;
+        int sums[3] = {0, 0, 0};
+        for (int k = 0; k < n; k++) {
+            sums[0] += (k - centre) * (int)hxp[k];
+            sums[1] += (k - centre) * (int)hyp[k];
+            sums[2] += (int)hxp[k];
+        }
+        finalise_flow(tail, pair0 + tid, hxp, hyp, sums);
+    }
 }
 
 }  // namespace
@@ -137,6 +216,27 @@ int launch_search_lane8(const SearchArgs &a, void *stream)
     if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_search_lane8, dim3((uint32_t)wgs), dim3(kThreads), 0,
                        static_cast<hipStream_t>(stream), a, items);
+    return (int)hipGetLastError();
+}
+
+// Pairs per workgroup of the grouped kernel; 0 = the grid does not qualify.
+int lane8_group(const SearchArgs &a)
+{
+    const int nb = a.grid.blocks();
+    if (!lane8_supported(a) || nb < 8 || nb > kThreads / 2) return 0;  // 2 .. 32 pairs per workgroup
+    return kThreads / nb;
+}
+
+int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream)
+{
+    if (a.n_pairs == 0) return 0;
+    const int ppw = lane8_group(a);
+    if (ppw == 0) return (int)hipErrorInvalidValue;
+    const int64_t wgs = (a.n_pairs + ppw - 1) / ppw;
+    if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
+    const int n = 2 * (2 * a.hist_range + 1) + 1;
+    hipLaunchKernelGGL(k_flow_lane8, dim3((uint32_t)wgs), dim3(kThreads), (size_t)ppw * 2 * n * sizeof(uint32_t),
+                       static_cast<hipStream_t>(stream), a, tail, ppw);
     return (int)hipGetLastError();
 }
 
