@@ -11,7 +11,19 @@ int main(int argc, char **argv)
     aof_params p;
     aof_params_px4flow(&p, w, h, 4, 30, 3000);
     std::vector<uint8_t> f[2];
-    for (int k = 0; k < 2; k++) { f[k].resize((size_t)w * h); for (auto &v : f[k]) v = rand() & 255; }
+    // a blurred random canvas cropped twice, 2 px / 1 px apart: every block has a clear match
+    std::vector<int> canvas((size_t)(w + 8) * (h + 8));
+    for (auto &v : canvas) v = rand() & 255;
+    for (int k = 0; k < 2; k++) {
+        f[k].resize((size_t)w * h);
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int acc = 0;
+                for (int dy = 0; dy < 3; dy++)
+                    for (int dx = 0; dx < 3; dx++) acc += canvas[(size_t)(y + dy + k) * (w + 8) + x + dx + 2 * k];
+                f[k][(size_t)y * w + x] = (uint8_t)(acc / 9);
+            }
+    }
     for (int mode = 0; mode < 4; mode++) {
         const int graph = !(mode & 1), generic = mode >> 1;
         aof_ctx *ctx;
