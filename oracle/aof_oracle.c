@@ -121,10 +121,51 @@ uint32_t orc_compute_diff(const uint8_t *img, int x, int y, int stride, int tile
     return acc;
 }
 
+/* Timing aid for bench.py's cpu_baseline leg: with orc_set_fast_sad(1) the 8x8 / 16x16 SAD
+ * uses the host's own SAD instruction (SSE2 psadbw) so that the CPU is not handicapped by a
+ * byte loop.  The checker (tests, smoke) never switches it on; tests/test_oracle.py pins it to
+ * the scalar loop. */
+static int g_fast_sad = 0;
+void orc_set_fast_sad(int on) { g_fast_sad = on != 0; }
+int orc_fast_sad_available(void)
+{
+#if defined(__SSE2__)
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+#if defined(__SSE2__)
+#include <emmintrin.h>
+static uint32_t sad_sse2(const uint8_t *pa, const uint8_t *pb, int stride, int tile)
+{
+    __m128i acc = _mm_setzero_si128();
+    if (tile == 8) {
+        for (int r = 0; r < 8; r += 2) {
+            const __m128i va = _mm_unpacklo_epi64(_mm_loadl_epi64((const __m128i *)(pa + (int64_t)r * stride)),
+                                                  _mm_loadl_epi64((const __m128i *)(pa + (int64_t)(r + 1) * stride)));
+            const __m128i vb = _mm_unpacklo_epi64(_mm_loadl_epi64((const __m128i *)(pb + (int64_t)r * stride)),
+                                                  _mm_loadl_epi64((const __m128i *)(pb + (int64_t)(r + 1) * stride)));
+            acc = _mm_add_epi64(acc, _mm_sad_epu8(va, vb));
+        }
+    } else {
+        for (int r = 0; r < 16; r++)
+            acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_loadu_si128((const __m128i *)(pa + (int64_t)r * stride)),
+                                                  _mm_loadu_si128((const __m128i *)(pb + (int64_t)r * stride))));
+    }
+    return (uint32_t)(_mm_cvtsi128_si32(acc) + _mm_cvtsi128_si32(_mm_srli_si128(acc, 8)));
+}
+#endif
+
 /* Published "compute_sad_8x8", generalised to BxB. */
 uint32_t orc_sad(const uint8_t *a, int ax, int ay, const uint8_t *b, int bx, int by,
                  int stride, int tile)
 {
+#if defined(__SSE2__)
+    if (g_fast_sad && (tile == 8 || tile == 16))
+        return sad_sse2(a + (int64_t)ay * stride + ax, b + (int64_t)by * stride + bx, stride, tile);
+#endif
     uint32_t acc = 0;
     for (int r = 0; r < tile; r++) {
         const uint8_t *pa = a + (int64_t)(ay + r) * stride + ax;

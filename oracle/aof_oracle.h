@@ -81,6 +81,10 @@ uint32_t orc_sad(const uint8_t *a, int ax, int ay, const uint8_t *b, int bx, int
                  int stride, int tile);
 void orc_subpixel(const uint8_t *a, int ax, int ay, const uint8_t *b, int bx, int by,
                   int stride, int tile, uint32_t acc[8]);
+/* bench.py's cpu_baseline leg only: SAD through the host's SAD instruction (SSE2 psadbw)
+ * instead of the byte loop; results are identical (tests/test_oracle.py). */
+void orc_set_fast_sad(int on);
+int orc_fast_sad_available(void);
 uint32_t orc_frame_mean(const uint8_t *img, int64_t n);
 void orc_pyramid_down(const uint8_t *src, int w, int h, uint8_t *dst);
 void orc_equalise(const uint8_t *src, int64_t n, int delta, uint8_t *dst);

@@ -52,6 +52,8 @@ def _load():
     lib.orc_hist_size.argtypes = [P(Params), C.c_int]
     lib.orc_compute_diff.restype = C.c_uint32
     lib.orc_compute_diff.argtypes = [VP, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.orc_set_fast_sad.argtypes = [C.c_int]
+    lib.orc_fast_sad_available.restype = C.c_int
     lib.orc_sad.restype = C.c_uint32
     lib.orc_sad.argtypes = [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.orc_subpixel.argtypes = [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]
@@ -153,6 +155,15 @@ def flow_batch(p: Params, prevs, curs, threads=0):
     if used < 0:
         raise ValueError("orc_flow_batch failed")
     return blocks, flows, used
+
+
+def set_fast_sad(on):
+    """bench.py's cpu_baseline leg only: SAD through the host's SAD instruction (SSE2 psadbw)."""
+    lib.orc_set_fast_sad(int(bool(on)))
+
+
+def fast_sad_available():
+    return bool(lib.orc_fast_sad_available())
 
 
 def compute_diff(img, x, y, tile=8):

@@ -344,3 +344,36 @@ def test_px4_unlimited_rate_and_wraparound(orc, synth):
     assert r0[0] == 0 and r1[0] == 255 and r2[0] == 255
     assert r2[1] == 13000
     assert r2[2] == pytest.approx(np.arctan2(np.float32(steps[1, 0]), np.float32(200.0)), abs=1e-7)
+
+
+def test_fast_sad_equals_byte_loop(orc, synth):
+    """bench.py times the oracle with the host's SAD instruction (SSE2 psadbw); the checker uses
+    the byte loop.  Both must give the same records and flows."""
+    if not orc.fast_sad_available():
+        pytest.skip("no SSE2 on this host")
+    rng = np.random.default_rng(5)
+    try:
+        for kw, w, h in ((dict(), 128, 96), (dict(tile=16, search=8, value_threshold=12000), 160, 128),
+                         (dict(pyramid_levels=2, mean_subtract=1, subpixel=1), 160, 128),
+                         (dict(grid_mode=1, subpixel=1, num_blocks=5), 64, 64)):
+            p = orc.default_params(w, h, **kw)
+            prevs, curs, _ = synth.make_batch(w, h, 6, 4, 77, noise=6, brightness=5)
+            curs[5] = rng.integers(0, 256, curs[5].shape, dtype=np.uint8)
+            out = []
+            for fast in (False, True):
+                orc.set_fast_sad(fast)
+                out.append([orc.flow_pair(p, prevs[i], curs[i]) for i in range(6)])
+            for a, b in zip(*out):
+                assert a["blocks"].tobytes() == b["blocks"].tobytes()
+                assert a["flow"].tobytes() == b["flow"].tobytes()
+        a = rng.integers(0, 256, (40, 48), dtype=np.uint8)
+        b = rng.integers(0, 256, (40, 48), dtype=np.uint8)
+        for tile in (8, 16):
+            for _ in range(50):
+                ax, ay, bx, by = (int(v) for v in rng.integers(0, 24, 4))
+                orc.set_fast_sad(False)
+                ref = orc.sad(a, ax, ay, b, bx, by, tile)
+                orc.set_fast_sad(True)
+                assert orc.sad(a, ax, ay, b, bx, by, tile) == ref
+    finally:
+        orc.set_fast_sad(False)
