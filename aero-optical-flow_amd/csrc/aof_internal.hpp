@@ -89,7 +89,8 @@ struct PyramidArgs {
 // hipError_t of the launch as int (0 = ok).
 int launch_pyramid(const PyramidArgs &a, void *stream);
 int launch_search_generic(const SearchArgs &a, void *stream);
-// K2b: half-pixel refinement of records written by an LDS-tiled integer search (tile 8 or 16;
+// K2b: half-pixel refinement of records written by an integer search (tile 8 or 16; today only
+// the 16x16 kernel needs it;
 // fills a.subdirs).
 int launch_refine(const SearchArgs &a, void *stream);
 // LDS-tiled lane-per-block kernel for B=8, S=4 on a dense grid without

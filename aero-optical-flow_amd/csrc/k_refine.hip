@@ -1,21 +1,13 @@
-// K2b -- half-pixel refinement after an LDS-tiled integer search (DESIGN.md "Spec":
-// Half-pixel refinement).
+// K2b -- half-pixel refinement as a separate pass (DESIGN.md "Spec": Half-pixel refinement).
 //
-// The LDS-tiled search kernels keep one result per lane and have no room for the ring of
-// the best match, so on configurations with half-pixel refinement they write the integer
-// records and this pass adds the direction byte.  One lane per block: the lane reads its
-// reference tile and the (B+2)^2 neighbourhood of its best match straight from global
-// memory (both frames were streamed by the search a moment ago and sit in L2), rows as
-// unaligned 8/16-byte loads.  The eight half-pixel images are built four pixels at a time
-// with v_lerp_u8 -- floor((a+b)/2) per byte, the UHADD8 of the published algorithm -- from
-// three row-shifted copies of each window row:
-//   H+(y) = lerp(P(y,x), P(y,x+1))   H-(y) = lerp(P(y,x), P(y,x-1))   C(y) = P(y,x)
-//   dir 0 = H+(y)              dir 4 = H-(y)
-//   dir 2 = lerp(C(y),C(y+1))  dir 6 = lerp(C(y),C(y-1))
-//   dir 1 = lerp(H+(y),H+(y+1))  dir 7 = lerp(H+(y-1),H+(y))
-//   dir 3 = lerp(H-(y),H-(y+1))  dir 5 = lerp(H-(y-1),H-(y))
-// so one pass over window rows y = -1..B with the previous row kept in registers feeds all
-// eight SADs.  Blocks the search skipped or rejected get direction 8 (none).
+// The 16x16 search kernel spreads a block over 17 lanes and keeps no ring of the best match,
+// so on configurations with half-pixel refinement it writes the integer records and this pass
+// adds the direction byte (the 8x8 kernels refine in place).  One lane per block, consecutive
+// lanes = consecutive (pair, block) items: the lane reads its reference tile and the (B+2)^2
+// neighbourhood of its best match straight from global memory (both frames were streamed by
+// the search a moment ago and sit in L2), rows as unaligned 8/16-byte loads, and feeds them to
+// the shared v_lerp_u8 arithmetic of aof_refine.hpp.  Blocks the search skipped or rejected get
+// direction 8 (none).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 #include "aof_refine.hpp"
