@@ -90,11 +90,10 @@ struct PyramidArgs {
 int launch_pyramid(const PyramidArgs &a, void *stream);
 int launch_search_generic(const SearchArgs &a, void *stream);
 // K2b: half-pixel refinement of records written by an integer search (tile 8 or 16; today only
-// the 16x16 kernel needs it;
-// fills a.subdirs).
+// the 16x16 kernel needs it); fills a.subdirs.
 int launch_refine(const SearchArgs &a, void *stream);
-// LDS-tiled lane-per-block kernel for B=8, S=4 on a dense grid without
-// half-pixel refinement.  tile8_supported() says whether `a` qualifies.
+// LDS-tiled lane-per-block kernel for B=8, S=4 on a dense grid whose rows are a multiple of
+// 16 bytes, half-pixel refinement included.  tile8_supported() says whether `a` qualifies.
 bool tile8_supported(const SearchArgs &a);
 int launch_search_tile8(const SearchArgs &a, void *stream);
 // Lane-per-block kernel straight from global memory for B=8, S=4 on ANY grid / width /
