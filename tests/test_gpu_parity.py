@@ -278,6 +278,56 @@ def test_small_frames(aof, orc, synth, gpu_device, case):
         assert set(np.unique(sub.cpu().numpy()[:8])) >= {0, 1, 2, 3, 4, 5, 6, 7}
 
 
+CANARY = [
+    dict(width=640, height=480),                                           # tile8, DMA staging
+    dict(width=640, height=480, subpixel=1),                               # tile8 + in-kernel refinement
+    dict(width=160, height=130, pyramid_levels=2, mean_subtract=1, subpixel=1),
+    dict(width=320, height=240, tile=16, search=8, value_threshold=12000, subpixel=1),  # tile16 + K2b
+    dict(px4=1, width=64, height=64),                                      # grouped lane8
+    dict(width=188, height=120, subpixel=1),                               # flat lane8
+    dict(width=100, height=90, search=3, subpixel=1),                      # generic
+]
+
+
+@pytest.mark.parametrize("case", range(len(CANARY)))
+def test_no_writes_outside_the_output_buffers(aof, synth, gpu_device, case):
+    """Every output (records, directions, flows, workspace) sits between two guard zones inside
+    one larger allocation; the guards must still hold their pattern after the launch."""
+    import torch
+    kw = dict(CANARY[case])
+    w, h = kw.pop("width"), kw.pop("height")
+    p = aof.px4flow_params(w, h, **kw) if kw.pop("px4", 0) else aof.default_params(w, h, **kw)
+    n, guard = 37, 4096
+    reach = 2 * p.search + 1 if p.pyramid_levels == 2 else p.search
+    m = 6
+    prevs, curs, _ = synth.make_batch(w, h, m, reach, 9100 + case, noise=4, brightness=5 if p.mean_subtract else 0)
+    reps = (n + m - 1) // m
+    tp = torch.from_numpy(prevs).to(gpu_device).repeat(reps, 1, 1)[:n].contiguous()
+    tc = torch.from_numpy(curs).to(gpu_device).repeat(reps, 1, 1)[:n].contiguous()
+    eng = aof.FlowEngine(p, 0)
+    nb = eng.nblocks(0)
+    sizes = dict(blocks=4 * n * nb, subdirs=n * nb, flows=16 * n, ws=aof.workspace_layout(p, n).total_bytes)
+    total = sum(guard + (v + 255) // 256 * 256 for v in sizes.values()) + guard
+    arena = torch.full((total,), 0xA5, dtype=torch.uint8, device=gpu_device)
+    off, views, gaps = guard, {}, [(0, guard)]
+    for k, v in sizes.items():
+        views[k] = arena[off:off + v]
+        end = off + (v + 255) // 256 * 256
+        gaps.append((off + v, end + guard))
+        off = end + guard
+    assert views["ws"].data_ptr() % 256 == 0 and views["blocks"].data_ptr() % 4 == 0
+    for mode in ("default", "pruned"):
+        if mode == "pruned":
+            eng.set_search_mode(aof.SEARCH_PRUNED)
+        eng.flow_batch(tp, tc, blocks=views["blocks"].view(torch.int32).view(n, nb),
+                       subdirs=views["subdirs"].view(n, nb) if p.subpixel else None,
+                       flows=views["flows"].view(n, 16), workspace=views["ws"])
+        torch.cuda.synchronize()
+        host = arena.cpu().numpy()
+        for lo, hi in gaps:
+            assert (host[lo:hi] == 0xA5).all(), (mode, lo, hi, np.nonzero(host[lo:hi] != 0xA5)[0][:8])
+
+
 def test_flat_and_saturated_frames(aof, orc, gpu_device):
     p = aof.default_params(128, 96)
     prevs = np.stack([np.full((96, 128), v, np.uint8) for v in (0, 77, 255)])
