@@ -212,8 +212,8 @@ def bench_ingest(args, aof, device, rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
