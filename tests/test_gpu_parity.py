@@ -421,6 +421,56 @@ def test_padded_pair_stride_and_caller_buffers(aof, orc, synth, gpu_device):
                          dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows)))
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(subpixel=1), dict(px4=1), dict(pyramid_levels=2, mean_subtract=1)])
+def test_unaligned_pair_stride_and_base(aof, orc, synth, gpu_device, kw):
+    """Frames at odd byte offsets and an odd pair stride: the strip kernels' alignment checks
+    must hand the batch to a kernel that reads byte-aligned sources."""
+    import torch
+    kw = dict(kw)
+    p = aof.px4flow_params(128, 96, **kw) if kw.pop("px4", 0) else aof.default_params(128, 96, **kw)
+    reach = 9 if p.pyramid_levels == 2 else 4
+    prevs, curs, _ = synth.make_batch(128, 96, 5, reach, 950, noise=3, brightness=4 if p.mean_subtract else 0)
+    stride, lead = 128 * 96 + 7, 3
+    bp = torch.zeros(lead + 5 * stride, dtype=torch.uint8, device=gpu_device)
+    bc = torch.zeros(lead + 5 * stride, dtype=torch.uint8, device=gpu_device)
+    for i in range(5):
+        bp[lead + i * stride:lead + i * stride + 128 * 96] = torch.from_numpy(prevs[i].ravel()).to(gpu_device)
+        bc[lead + i * stride:lead + i * stride + 128 * 96] = torch.from_numpy(curs[i].ravel()).to(gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    sub = torch.full((5, eng.nblocks(0)), 99, dtype=torch.uint8, device=gpu_device) if p.subpixel else None
+    blocks, flows, _ = eng.flow_batch(bp[lead:], bc[lead:], n_pairs=5, pair_stride=stride, subdirs=sub)
+    torch.cuda.synchronize()
+    check_against_oracle(aof, orc, p, prevs, curs, dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows)),
+                         subdirs=sub.cpu().numpy() if sub is not None else None)
+
+
+def test_very_large_batch_of_small_frames(aof, orc, synth, gpu_device):
+    """100 000 pairs of configs[0] in one launch: grouped lane8 workgroups (ragged last one) and
+    the generic kernel's y/z grid split agree on every record; a sample is checked against the
+    oracle."""
+    import torch
+    p = aof.px4flow_params(64, 64)
+    n, m = 100_003, 40
+    prevs, curs, _ = synth.make_batch(64, 64, m, 4, 990, noise=3)
+    reps = (n + m - 1) // m
+    tp = torch.from_numpy(prevs).to(gpu_device).repeat(reps, 1, 1)[:n].contiguous()
+    tc = torch.from_numpy(curs).to(gpu_device).repeat(reps, 1, 1)[:n].contiguous()
+    outs = []
+    for generic in (False, True):
+        eng = aof.FlowEngine(p, 0)
+        eng.force_generic(generic)
+        sub = torch.full((n, 25), 99, dtype=torch.uint8, device=gpu_device)
+        blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+        torch.cuda.synchronize()
+        outs.append((blocks.cpu().numpy(), flows.cpu().numpy(), sub.cpu().numpy()))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert a.tobytes() == b.tobytes()
+    got = dict(blocks=aof.blocks_view(torch.from_numpy(outs[0][0][-m:])), flows=aof.flows_view(torch.from_numpy(outs[0][1][-m:])))
+    idx = [(n - m + i) % m for i in range(m)]
+    check_against_oracle(aof, orc, p, prevs[idx], curs[idx], got, subdirs=outs[0][2][-m:])
+
+
 def test_empty_batch_and_errors(aof, gpu_device):
     import torch
     p = aof.default_params(128, 96)
