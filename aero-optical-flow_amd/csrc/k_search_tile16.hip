@@ -39,18 +39,37 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     const int tid = threadIdx.x;
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * a.h));
 
-    uint8_t *s_cur = smem;                           // frame rows [16*by, 16*by + 32)
+    // Level 0 under a predictor (px, py): the block row's windows move by py rows and px columns.
+    // As in k_search_tile8 the cur rows are staged PRE-SHIFTED by px mod 16, so that LDS column c
+    // holds frame column c + sh and every window is again 16-byte aligned at LDS column
+    // 16*(bx + (px >> 4)); rows pushed outside the frame skip the whole block row.
+    int px = 0, py = 0;
+    if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
+    const int sh = px & 15;                                       // floor-mod
+    uint8_t *s_cur = smem;                           // frame rows [16*by + py, +32)
     uint8_t *s_prev = smem + (size_t)32 * W;         // frame rows [16*by + 8, +16)
     uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + (size_t)48 * W);
     // Half-pixel refinement moves the grid origin to S+1 = 9: the same geometry on a frame whose
     // origin is moved by (1, 1) -- the flat copies start W+1 bytes later (byte-aligned loads);
     // the grid keeps every window inside the smaller frame.  K2b adds the directions.
     const int org = a.grid.x0 - 8;
+    const int H = a.h - 2 * org, Wb = W - 2 * org;               // the moved frame
     const int64_t org_off = (int64_t)org * (W + 1);
-    const uint8_t *g_cur = a.cur + pair * a.pair_stride + org_off + (int64_t)(16 * by) * W;
+    const int yc0 = 16 * by + py;                                 // moved-frame row of LDS cur row 0
+    const bool rows_ok = yc0 >= 0 && yc0 + 32 <= H;               // wave-uniform: the whole block row
+    const uint8_t *g_cur = a.cur + pair * a.pair_stride + org_off + (int64_t)yc0 * W + sh;
     const uint8_t *g_prev = a.prev + pair * a.pair_stride + org_off + (int64_t)(16 * by + 8) * W;
-    const int cur_chunks = 32 * (W / 16), prev_chunks = 16 * (W / 16);
-    if (org != 0) {
+    int cur_chunks = rows_ok ? 32 * (W / 16) : 0;
+    const int prev_chunks = 16 * (W / 16);
+    // the displaced copy ends sh bytes past its last row: bytewise when that is the frame's end
+    // (with the moved origin the frame's own last row and column absorb the over-read)
+    const bool tail_guard = sh != 0 && org == 0 && rows_ok && yc0 + 32 == H;
+    if (tail_guard) {
+        cur_chunks -= 1;
+        if (tid < 16 - sh)
+            s_cur[(size_t)cur_chunks * 16 + tid] = (uint8_t)clamp_u8((int)g_cur[(size_t)cur_chunks * 16 + tid] + delta);
+    }
+    if (org != 0 || sh != 0) {  // byte-aligned source: through registers
         for (int c = tid; c < cur_chunks + prev_chunks; c += kThreads) {
             const bool is_cur = c < cur_chunks;
             const int cc = is_cur ? c : c - cur_chunks;
@@ -72,16 +91,19 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
             *reinterpret_cast<uint4 *>(s_cur + (size_t)c * 16) = v;
         }
     }
-    if (org == 0)
+    if (org == 0 && sh == 0)
         for (int c = tid; c < prev_chunks; c += kThreads)
             *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) =
                 *reinterpret_cast<const uint4 *>(g_prev + (size_t)c * 16);
     for (int b = tid; b < nx; b += kThreads) s_best[b] = 0xFFFFFFFFu;
     __syncthreads();
 
-    const int items = kSide * nx;
+    const int items = rows_ok ? kSide * nx : 0;
     for (int item = tid; item < items; item += kThreads) {
         const int dyi = item / nx, bx = item - dyi * nx;
+        const int xf = 16 * bx + px;                  // moved-frame column of the window start
+        if (xf < 0 || xf + 32 > Wb) continue;         // window leaves the frame: block skipped below
+        const int xs = xf - sh;                       // its 16-aligned LDS column
         // reference tile: 16 rows x 4 dwords at frame column 16*bx + 8
         uint32_t ref[16][4];
 #pragma unroll
@@ -92,7 +114,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         }
         u64 acc[4] = {0, 0, 0, 0};                    // offsets 4g .. 4g+3, packed u16
         uint32_t acc16 = (uint32_t)(dyi * kSide + 16);  // offset 16 as sad<<16 | idx
-        const uint8_t *win = s_cur + (size_t)dyi * W + 16 * bx;
+        const uint8_t *win = s_cur + (size_t)dyi * W + xs;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint4 *p = reinterpret_cast<const uint4 *>(win + (size_t)r * W);
@@ -138,11 +160,12 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
             diff = __builtin_amdgcn_sad_u8(mid[r], __builtin_amdgcn_perm(0u, mid[r], 0x03030201u), diff);
         aof_block rec;
         rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
-        if (diff >= (uint32_t)a.feature_threshold) {
+        const int xf = 16 * bx + px;
+        if (rows_ok && xf >= 0 && xf + 32 <= Wb && diff >= (uint32_t)a.feature_threshold) {
             const uint32_t best = s_best[bx];
             const int idx = (int)(best & 0xFFFFu);
-            rec.dx = (int8_t)(idx % kSide - 8);
-            rec.dy = (int8_t)(idx / kSide - 8);
+            rec.dx = (int8_t)(px + idx % kSide - 8);
+            rec.dy = (int8_t)(py + idx / kSide - 8);
             rec.sad = (uint16_t)(best >> 16);
         }
         a.blocks[pair * (int64_t)(nx * ny) + (int64_t)by * nx + bx] = rec;
@@ -155,7 +178,7 @@ size_t tile16_lds(const SearchArgs &a) { return (size_t)48 * a.w + 4 * (size_t)a
 
 bool tile16_supported(const SearchArgs &a)
 {
-    if (a.tile != 16 || a.search != 8 || a.pred) return false;
+    if (a.tile != 16 || a.search != 8) return false;
     const int org = a.subpixel ? 1 : 0;  // origin S+1: K2b follows
     if (a.grid.x0 != 8 + org || a.grid.y0 != 8 + org || a.grid.step_x != 16 || a.grid.step_y != 16) return false;
     if (a.w % 16 || a.pair_stride % 16) return false;

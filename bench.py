@@ -41,6 +41,8 @@ WORKLOADS = {
             64, 64, dict(_px4flow=1), 4),
     "c5": ("C5 1280x960 pairs, 16x16 SAD, +-8 search",
            1280, 960, dict(tile=16, search=8, value_threshold=12000), 8),
+    "c5p": ("C5 geometry with the 2-level mean-subtracted pyramid",
+            1280, 960, dict(tile=16, search=8, value_threshold=12000, pyramid_levels=2, mean_subtract=1), 17),
     "c5h": ("C5 geometry with half-pixel refinement (origin 9)",
             1280, 960, dict(tile=16, search=8, value_threshold=12000, subpixel=1), 8),
 }
