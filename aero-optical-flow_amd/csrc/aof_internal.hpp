@@ -101,7 +101,7 @@ int launch_search_tile8(const SearchArgs &a, void *stream);
 // included.
 bool lane8_supported(const SearchArgs &a);
 int launch_search_lane8(const SearchArgs &a, void *stream);
-// Grids of 8..128 blocks: a workgroup owns whole pairs and also writes their flow records (no K3).
+// Grids of 8..256 blocks: a workgroup owns whole pairs and also writes their flow records (no K3).
 int lane8_group(const SearchArgs &a);  // pairs per workgroup, 0 = not applicable
 int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream);
 // LDS-tiled (block, dy)-per-lane kernel for B=16, S=8 on a dense grid (any predictor).

@@ -223,7 +223,7 @@ int launch_search_lane8(const SearchArgs &a, void *stream)
 int lane8_group(const SearchArgs &a)
 {
     const int nb = a.grid.blocks();
-    if (!lane8_supported(a) || nb < 8 || nb > kThreads / 2) return 0;  // 2 .. 32 pairs per workgroup
+    if (!lane8_supported(a) || nb < 8 || nb > kThreads) return 0;  // 1 .. 32 pairs per workgroup
     return kThreads / nb;
 }
 

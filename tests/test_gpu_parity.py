@@ -187,6 +187,8 @@ SHAPES = [
     dict(width=160, height=130, tile=16, search=8, value_threshold=12000, subpixel=1, mean_subtract=1),
     dict(width=320, height=256, tile=16, search=8, value_threshold=12000, pyramid_levels=2),          # tile16 under a predictor
     dict(width=320, height=260, tile=16, search=8, value_threshold=12000, pyramid_levels=2, mean_subtract=1, subpixel=1),
+    dict(width=152, height=120),                                  # 252 blocks, rows of 152 bytes: one pair per lane8 workgroup
+    dict(width=152, height=120, subpixel=1, mean_subtract=1),
     dict(width=80, height=64, search=2),
     dict(width=80, height=64, search=7, min_valid=0),
     dict(width=1280, height=64),                                  # wide rows: strip planning
