@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOF_LIB") or os.path.join(_HERE, "csrc", "libaof.so")
 
 GRID_DENSE, GRID_PX4FLOW = 0, 1
-SEARCH_EXHAUSTIVE, SEARCH_PRUNED = 0, 1
+SEARCH_EXHAUSTIVE, SEARCH_PRUNED, SEARCH_EXHAUSTIVE_STRIPS = 0, 1, 2
 SAD_SKIPPED = 0xFFFF
 FLAG_FLOW_VALID, FLAG_PRED_VALID = 1, 2
 K_PYRAMID, K_SEARCH_L1, K_REDUCE_L1, K_SEARCH, K_REDUCE = range(5)
@@ -248,7 +248,8 @@ class FlowEngine:
         self._check(lib.aof_set_force_generic(self._ctx, int(on)))
 
     def set_search_mode(self, mode):
-        """SEARCH_EXHAUSTIVE (default) or SEARCH_PRUNED (exact, data-dependent rate)."""
+        """SEARCH_EXHAUSTIVE (default), SEARCH_PRUNED (exact, data-dependent rate) or
+        SEARCH_EXHAUSTIVE_STRIPS (exhaustive search in the LDS-strip kernel)."""
         self._check(lib.aof_set_search_mode(self._ctx, int(mode)))
 
     def set_profiling(self, on=True, kernels=None):

@@ -28,7 +28,6 @@ struct aof_ctx {
     bool profiling;
     uint32_t profile_mask;
     int search_mode;
-    const char *variant;
     char err[256];
     hipEvent_t (*ev)[AOF_PROFILE_RING][2];  // [AOF_K_COUNT][ring][start,stop], created on demand
     int64_t ev_count[AOF_K_COUNT];           // launches timed since profiling was switched on
@@ -130,7 +129,11 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, uint32_t *parts
     *parts_used = nullptr;
     *nstrips = 0;
     *reduced = false;
-    if (!ctx->force_generic && tile8_supported(a)) {
+    // The LDS-strip kernel serves the pruned search and the explicit EXHAUSTIVE_STRIPS mode; the
+    // default exhaustive search of 8x8 tiles runs lane-per-block straight from L2 (measured
+    // faster on every dense configuration: full lane use, no staging phases, no barriers).
+    const bool strips = ctx->search_mode != AOF_SEARCH_EXHAUSTIVE;
+    if (!ctx->force_generic && strips && tile8_supported(a)) {
         a.hist_parts = parts;   // the strips vote (half-pixel offsets included): K3 sums them
         *parts_used = parts;
         *nstrips = plan_tile8(a.w, a.grid.nx, a.grid.ny).nstrips;
@@ -176,11 +179,6 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
     if (p->pyramid_levels == 2) grid_for_level(*p, 1, &ctx->g1);
     std::snprintf(ctx->err, sizeof(ctx->err), "ok");
 
-    // which search kernel will level 0 use? (probe with aligned dummy pointers)
-    SearchArgs probe = search_args(ctx, 0, nullptr, nullptr, (int64_t)p->width * p->height, nullptr,
-                                   nullptr, nullptr, nullptr, 1);
-    ctx->variant = tile8_supported(probe) ? "tile8_lds"
-                   : (tile16_supported(probe) ? "tile16_lds" : (lane8_supported(probe) ? "lane8" : "generic"));
     *out = ctx;
     return 0;
 }
@@ -222,7 +220,14 @@ int aof_get_params(const aof_ctx *ctx, aof_params *out)
 const char *aof_search_variant(const aof_ctx *ctx)
 {
     if (!ctx) return "";
-    return ctx->force_generic ? "generic" : ctx->variant;
+    if (ctx->force_generic) return "generic";
+    // which search kernel will level 0 use? (probe with aligned dummy pointers)
+    const aof_params &p = ctx->params;
+    SearchArgs probe = search_args(ctx, 0, nullptr, nullptr, (int64_t)p.width * p.height, nullptr, nullptr,
+                                   nullptr, nullptr, 1);
+    if (ctx->search_mode != AOF_SEARCH_EXHAUSTIVE && tile8_supported(probe)) return "tile8_lds";
+    if (tile16_supported(probe)) return "tile16_lds";
+    return lane8_supported(probe) ? "lane8" : "generic";
 }
 
 int aof_set_force_generic(aof_ctx *ctx, int on)
@@ -234,7 +239,8 @@ int aof_set_force_generic(aof_ctx *ctx, int on)
 
 int aof_set_search_mode(aof_ctx *ctx, int mode)
 {
-    if (!ctx || (mode != AOF_SEARCH_EXHAUSTIVE && mode != AOF_SEARCH_PRUNED)) return -EINVAL;
+    if (!ctx || (mode != AOF_SEARCH_EXHAUSTIVE && mode != AOF_SEARCH_PRUNED && mode != AOF_SEARCH_EXHAUSTIVE_STRIPS))
+        return -EINVAL;
     if (mode != ctx->search_mode) {  // captured graphs hold the old kernel
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }

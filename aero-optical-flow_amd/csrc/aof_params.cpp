@@ -52,10 +52,9 @@ int g_lab_rb = 0, g_lab_dyg = 0;
 // 4-wave one (rb=3, 91 %) because fewer workgroups fit a CU and staging stops
 // overlapping with the search (profiles/r01_b_k2_lab.txt).  One lane per block
 // (dyg = 9): three lanes per block measured 11 % slower (profiles/r01_c_k2_lab_dyg.txt).
-Tile8Plan plan_tile8(int w, int nx, int ny)
+static Tile8Plan plan_tile8_budget(int w, int nx, int ny, size_t kLdsBudget)
 {
     const int kMaxThreads = 512;
-    const size_t kLdsBudget = 80 * 1024;  // two workgroups per CU at the least
     Tile8Plan best = {0, 0, 0, 0, 0};
     double best_eff = -1.0;
     int dyg = 9;
@@ -78,6 +77,15 @@ Tile8Plan plan_tile8(int w, int nx, int ny)
         if (eff > best_eff + 1e-9) { best_eff = eff; best = {rb, threads, nstrips, dyg, lds}; }
     }
     return best;
+}
+
+Tile8Plan plan_tile8(int w, int nx, int ny)
+{
+    // two workgroups per CU at the least; very wide rows (4K frames: one block row is 100 KB
+    // of tiles) get the whole LDS of a CU rather than no strip plan at all
+    Tile8Plan p = plan_tile8_budget(w, nx, ny, 80 * 1024);
+    if (p.rb == 0) p = plan_tile8_budget(w, nx, ny, 156 * 1024);
+    return p;
 }
 
 bool tile8_geometry(const aof_params &p, int level)

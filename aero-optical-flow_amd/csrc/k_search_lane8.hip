@@ -19,7 +19,10 @@ namespace aof {
 
 namespace {
 
-constexpr int kThreads = 256;
+#ifndef AOF_LANE8_THREADS
+#define AOF_LANE8_THREADS 256
+#endif
+constexpr int kThreads = AOF_LANE8_THREADS;
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 {
@@ -29,12 +32,14 @@ __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)h
 
 // One block: record (and direction) written to global memory and returned for the votes.
 // Returns the half-pixel direction (8 = none).
+template <bool SUBPIXEL>
 __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, int blk, int64_t item,
                                             aof_block &rec)
 {
     const int bx = blk % a.grid.nx, by = blk / a.grid.nx;
     const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y;
-    const int W = a.w, m = a.subpixel ? 1 : 0;
+    const int W = a.w;
+    constexpr int m = SUBPIXEL ? 1 : 0;
     int px = 0, py = 0;
     if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(a.w * a.h));
@@ -45,7 +50,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
     const int wx0 = i + px - 4, wy0 = j + py - 4;
     if (wx0 - m < 0 || wy0 - m < 0 || wx0 + 16 + m > a.w || wy0 + 16 + m > a.h) {
         *out = __builtin_bit_cast(uint32_t, rec);
-        if (a.subdirs) a.subdirs[item] = 8;
+        if (SUBPIXEL) a.subdirs[item] = 8;
         return 8;
     }
     const uint8_t *pr = a.prev + pair * a.pair_stride + (int64_t)j * W + i;
@@ -72,7 +77,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
     }
     if (diff < (uint32_t)a.feature_threshold) {
         *out = __builtin_bit_cast(uint32_t, rec);
-        if (a.subdirs) a.subdirs[item] = 8;
+        if (SUBPIXEL) a.subdirs[item] = 8;
         return 8;
     }
 
@@ -121,7 +126,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
     // Half-pixel refinement of accepted blocks: the ring of the best match, rows -1..8 and
     // bytes -1..8, again straight from global memory (the lines were touched a moment ago).
     int subdir = 8;
-    if (a.subdirs) {
+    if constexpr (SUBPIXEL) {
         if ((uint32_t)rec.sad < (uint32_t)a.value_threshold) {
             const uint8_t *ring = pc + (idx / 9 - 1) * W + (idx % 9 - 1);
             uint32_t rows[10][3];
@@ -153,20 +158,24 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
 // Flat mapping: 256 consecutive (pair, block) items per workgroup; K3 follows.
 // Two to three waves per SIMD: the kernel trades occupancy for registers, so that a lane has
 // all 24 of its row loads in flight at once (one memory round trip per block instead of 16).
-__global__ __launch_bounds__(kThreads, 2) void k_search_lane8(SearchArgs a, int64_t items)
+template <bool SUBPIXEL>
+__global__ __launch_bounds__(kThreads, 4) void k_search_lane8(SearchArgs a, int64_t items, uint32_t total_wgs)
 {
-    const int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    // consecutive workgroups = consecutive block rows of one pair: keep them on one XCD, whose L2
+    // then serves the search rows that vertically adjacent blocks share
+    const int64_t item = (int64_t)xcd_remap(blockIdx.x, total_wgs) * kThreads + threadIdx.x;
     if (item >= items) return;
     const int nb = a.grid.blocks();
     const int64_t pair = item / nb;
     aof_block rec;
-    (void)search_block(a, pair, (int)(item - pair * nb), item, rec);
+    (void)search_block<SUBPIXEL>(a, pair, (int)(item - pair * nb), item, rec);
 }
 
 // Grouped mapping for grids of a few dozen blocks (the published sparse grid): a workgroup owns
 // `ppw` WHOLE pairs, so their votes meet in LDS and one lane per pair finalises the flow record
 // -- no K3 launch, no second pass over the records.
-__global__ __launch_bounds__(kThreads, 2) void k_flow_lane8(SearchArgs a, FlowTail tail, int ppw)
+template <bool SUBPIXEL>
+__global__ __launch_bounds__(kThreads, 4) void k_flow_lane8(SearchArgs a, FlowTail tail, int ppw)
 {
     extern __shared__ uint32_t s_votes[];  // [ppw][2][n]
     const int nb = a.grid.blocks(), tid = threadIdx.x;
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_flow_lane8(SearchArgs a, FlowTa
     aof_block rec;
     rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
     int subdir = 8;
-    if (live) subdir = search_block(a, pair0 + p, blk, (pair0 + p) * nb + blk, rec);
+    if (live) subdir = search_block<SUBPIXEL>(a, pair0 + p, blk, (pair0 + p) * nb + blk, rec);
     const bool ok = live && (uint32_t)rec.sad < (uint32_t)a.value_threshold;  // skipped = 0xFFFF
     const int hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
     const int hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
@@ -214,8 +223,9 @@ int launch_search_lane8(const SearchArgs &a, void *stream)
     const int64_t items = a.n_pairs * a.grid.blocks();
     const int64_t wgs = (items + kThreads - 1) / kThreads;
     if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_search_lane8, dim3((uint32_t)wgs), dim3(kThreads), 0,
-                       static_cast<hipStream_t>(stream), a, items);
+    if (a.subpixel && !a.subdirs) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(a.subpixel ? k_search_lane8<true> : k_search_lane8<false>, dim3((uint32_t)wgs),
+                       dim3(kThreads), 0, static_cast<hipStream_t>(stream), a, items, (uint32_t)wgs);
     return (int)hipGetLastError();
 }
 
@@ -235,7 +245,9 @@ int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream)
     const int64_t wgs = (a.n_pairs + ppw - 1) / ppw;
     if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     const int n = 2 * (2 * a.hist_range + 1) + 1;
-    hipLaunchKernelGGL(k_flow_lane8, dim3((uint32_t)wgs), dim3(kThreads), (size_t)ppw * 2 * n * sizeof(uint32_t),
+    if (a.subpixel && !a.subdirs) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(a.subpixel ? k_flow_lane8<true> : k_flow_lane8<false>, dim3((uint32_t)wgs), dim3(kThreads),
+                       (size_t)ppw * 2 * n * sizeof(uint32_t),
                        static_cast<hipStream_t>(stream), a, tail, ppw);
     return (int)hipGetLastError();
 }

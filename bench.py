@@ -41,6 +41,8 @@ WORKLOADS = {
             64, 64, dict(_px4flow=1), 4),
     "c5": ("C5 1280x960 pairs, 16x16 SAD, +-8 search",
            1280, 960, dict(tile=16, search=8, value_threshold=12000), 8),
+    "c4k": ("3840x2160 grey pairs, 8x8 SAD, +-4 search, dense grid",
+            3840, 2160, dict(), 4),
     "c5p": ("C5 geometry with the 2-level mean-subtracted pyramid",
             1280, 960, dict(tile=16, search=8, value_threshold=12000, pyramid_levels=2, mean_subtract=1), 17),
     "c5h": ("C5 geometry with half-pixel refinement (origin 9)",
@@ -219,7 +221,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
-    ap.add_argument("--search", default="exhaustive", choices=["exhaustive", "pruned"],
+    ap.add_argument("--search", default="exhaustive", choices=["exhaustive", "pruned", "strips"],
                     help="exhaustive (default, the data-independent rate the metric is quoted on) or "
                          "pruned: exact partial-distortion elimination, same records, rate depends on "
                          "the images (fast on these clean synthetic translations)")
@@ -269,6 +271,8 @@ def main():
     eng = aof.FlowEngine(p, dev_index)
     if args.search == "pruned":
         eng.set_search_mode(aof.SEARCH_PRUNED)
+    elif args.search == "strips":
+        eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
     if args.force_generic:
         eng.force_generic(True)
     if args.scaling == "strong":
@@ -384,13 +388,16 @@ def main():
                      "algorithmic_bytes_per_pair": alg_bytes, "pairs_per_launch": n,
                      # nominal abs-diffs of the exhaustive scan; meaningless when candidates are pruned
                      "abs_diff_per_s": round(aof.abs_diffs(p) * n / (k2_ms * 1e-3), 1)
-                     if args.search == "exhaustive" else None},
+                     if args.search != "pruned" else None},
         "kernels_ms": per_kernel,
     }
 
     # ---- secondary, clearly separate: the opt-in exact-pruning search on the same batch ----
     # (same records bit for bit; data-dependent rate, so never the headline `value`)
-    if args.search == "exhaustive" and eng.variant == "tile8_lds":
+    eng.set_search_mode(aof.SEARCH_PRUNED)
+    pruned_available = eng.variant == "tile8_lds"
+    eng.set_search_mode(aof.SEARCH_EXHAUSTIVE)
+    if args.search == "exhaustive" and pruned_available and not args.force_generic:
         ref_blocks = blocks.clone()
         eng.set_search_mode(aof.SEARCH_PRUNED)
         eng.set_profiling(True)
@@ -409,7 +416,7 @@ def main():
             "per_gpu_value": round(n * args.steps / dt, 1), "unit": "frame-pairs/s", "kernel_ms": round(pk2, 5),
             "roofline_frac": round(alg_bytes * n / (pk2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "records_identical_to_exhaustive": bool(torch.equal(ref_blocks, blocks)),
-            "note": "opt-in AOF_SEARCH_PRUNED (partial-distortion elimination): bit-identical records, "
+            "note": "opt-in AOF_SEARCH_PRUNED (partial-distortion elimination, LDS-strip kernel): bit-identical records, "
                     "rate depends on the images; not the headline"}
         state["i"] = 1  # flows2[0] holds the latest records
 

@@ -124,16 +124,20 @@ int aof_get_params(const aof_ctx *ctx, aof_params *out);
 const char *aof_search_variant(const aof_ctx *ctx);
 /* Force the generic search kernel (tests compare the two device paths). */
 int aof_set_force_generic(aof_ctx *ctx, int on);
-/* Search strategy of the LDS-tiled 8x8 kernel.  Both return bit-identical records.
+/* Search strategy for 8x8 tiles, +-4.  All three return bit-identical records.
  * EXHAUSTIVE (default): all 81 candidates of every block are summed completely -- a
- *   data-independent rate, the one BASELINE's metric is quoted on.
- * PRUNED: exact partial-distortion elimination.  The nine dy rows are visited outwards
- *   from dy = 0; after two of a row's eight row pairs a wave drops the row when no lane's
- *   partial SAD can still beat its best (a partial sum only grows).  The rate then depends
- *   on the images: fast when blocks have a clear match near the centre, slower than the
- *   exhaustive kernel on noise. */
+ *   data-independent rate, the one BASELINE's metric is quoted on.  The library picks the
+ *   fastest kernel for the configuration (lane-per-block from L2 for 8x8 tiles).
+ * PRUNED: exact partial-distortion elimination in the LDS-strip kernel.  The nine dy rows are
+ *   visited outwards from dy = 0; after two of a row's eight row pairs a wave drops the row
+ *   when no lane's partial SAD can still beat its best (a partial sum only grows).  The rate
+ *   then depends on the images: fast when blocks have a clear match near the centre, slower
+ *   than the exhaustive search on noise.
+ * EXHAUSTIVE_STRIPS: the exhaustive search in the LDS-strip kernel (kept for comparison and as
+ *   the per-wave fallback of PRUNED). */
 #define AOF_SEARCH_EXHAUSTIVE 0
 #define AOF_SEARCH_PRUNED 1
+#define AOF_SEARCH_EXHAUSTIVE_STRIPS 2
 int aof_set_search_mode(aof_ctx *ctx, int mode);
 
 /* ---- the hot path, device-resident (batched) ----

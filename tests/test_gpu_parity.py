@@ -10,11 +10,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_gpu(aof, p, prevs, curs, device, force_generic=False, want_ws=False):
+def run_gpu(aof, p, prevs, curs, device, force_generic=False, want_ws=False, strips=False):
     import torch
     eng = aof.FlowEngine(p, 0)
     if force_generic:
         eng.force_generic(True)
+    if strips:
+        eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
     tp = torch.from_numpy(np.ascontiguousarray(prevs)).to(device)
     tc = torch.from_numpy(np.ascontiguousarray(curs)).to(device)
     blocks, flows, ws = eng.flow_batch(tp, tc)
@@ -66,8 +68,11 @@ def test_c1_64x64_dense(aof, orc, synth, gpu_device):
     p = aof.default_params(64, 64)
     prevs, curs, shifts = synth.make_batch(64, 64, 16, 4, 100)
     got = run_gpu(aof, p, prevs, curs, gpu_device)
-    assert got["variant"] == "tile8_lds"
+    assert got["variant"] == "lane8"
     check_against_oracle(aof, orc, p, prevs, curs, got)
+    strip = run_gpu(aof, p, prevs, curs, gpu_device, strips=True)
+    assert strip["variant"] == "tile8_lds"
+    assert strip["blocks"].tobytes() == got["blocks"].tobytes() and strip["flows"].tobytes() == got["flows"].tobytes()
     # analytic known answer, independent of any implementation
     for i in range(16):
         assert (got["blocks"][i]["dx"] == shifts[i, 0]).all() and (got["blocks"][i]["dy"] == shifts[i, 1]).all()
@@ -81,9 +86,12 @@ def test_c2_vga_8x8_bit_exact(aof, orc, synth, gpu_device, noise, brightness):
     p = aof.default_params(640, 480)
     prevs, curs, shifts = synth.make_batch(640, 480, 5, 4, 200 + noise, noise=noise, brightness=brightness)
     got = run_gpu(aof, p, prevs, curs, gpu_device)
-    assert got["variant"] == "tile8_lds"
+    assert got["variant"] == "lane8"
     assert got["blocks"].shape == (5, 4661)
     check_against_oracle(aof, orc, p, prevs, curs, got)
+    strip = run_gpu(aof, p, prevs, curs, gpu_device, strips=True)
+    assert strip["variant"] == "tile8_lds"
+    check_against_oracle(aof, orc, p, prevs, curs, strip)
 
 
 def test_c2_generic_kernel_agrees(aof, orc, synth, gpu_device):
@@ -218,7 +226,7 @@ def test_shapes_and_options(aof, orc, synth, gpu_device, case):
                          subdirs=sub.cpu().numpy() if sub is not None else None)
 
 
-@pytest.mark.parametrize("mode", ["exhaustive", "pruned", "generic"])
+@pytest.mark.parametrize("mode", ["exhaustive", "strips", "pruned", "generic"])
 @pytest.mark.parametrize("kw", [dict(), dict(pyramid_levels=2, mean_subtract=1)])
 def test_vga_dense_half_pixel(aof, orc, synth, gpu_device, mode, kw):
     """Dense grid with half-pixel refinement (origin S+1): the LDS-tiled integer search on the
@@ -230,11 +238,15 @@ def test_vga_dense_half_pixel(aof, orc, synth, gpu_device, mode, kw):
     for i, half in enumerate([(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1), (1, -1), (-1, 1)]):
         prevs[i], curs[i], _ = synth.make_pair(640, 480, 4, 50 + i, shift=(2 - i % 5, i % 3 - 1), half=half)
     eng = aof.FlowEngine(p, 0)
-    assert eng.variant == "tile8_lds"
+    assert eng.variant == "lane8"
     if mode == "generic":
         eng.force_generic(True)
     elif mode == "pruned":
         eng.set_search_mode(aof.SEARCH_PRUNED)
+        assert eng.variant == "tile8_lds"
+    elif mode == "strips":
+        eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
+        assert eng.variant == "tile8_lds"
     tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
     sub = torch.full((n, eng.nblocks(0)), 99, dtype=torch.uint8, device=gpu_device)
     blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
@@ -320,9 +332,11 @@ def test_no_writes_outside_the_output_buffers(aof, synth, gpu_device, case):
         gaps.append((off + v, end + guard))
         off = end + guard
     assert views["ws"].data_ptr() % 256 == 0 and views["blocks"].data_ptr() % 4 == 0
-    for mode in ("default", "pruned"):
+    for mode in ("default", "strips", "pruned"):
         if mode == "pruned":
             eng.set_search_mode(aof.SEARCH_PRUNED)
+        elif mode == "strips":
+            eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
         eng.flow_batch(tp, tc, blocks=views["blocks"].view(torch.int32).view(n, nb),
                        subdirs=views["subdirs"].view(n, nb) if p.subpixel else None,
                        flows=views["flows"].view(n, 16), workspace=views["ws"])

@@ -12,8 +12,10 @@ pytestmark = pytest.mark.gpu
 def run(aof, p, prevs, curs, device, mode, hint_fill=None, reps=1):
     import torch
     eng = aof.FlowEngine(p, 0)
+    # the strip kernel serves PRUNED and EXHAUSTIVE_STRIPS; plain EXHAUSTIVE requests become the
+    # latter here so that both code paths of that kernel are compared
+    eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS if mode == aof.SEARCH_EXHAUSTIVE else mode)
     assert eng.variant == "tile8_lds"
-    eng.set_search_mode(mode)
     tp, tc = torch.from_numpy(prevs).to(device), torch.from_numpy(curs).to(device)
     n = prevs.shape[0]
     L = aof.workspace_layout(p, n)
