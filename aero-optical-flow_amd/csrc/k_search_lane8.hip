@@ -19,10 +19,7 @@ namespace aof {
 
 namespace {
 
-#ifndef AOF_LANE8_THREADS
-#define AOF_LANE8_THREADS 256
-#endif
-constexpr int kThreads = AOF_LANE8_THREADS;
+constexpr int kThreads = 256;  // 64, 128 and 256 measure the same, 512 is 4 % slower
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 {
