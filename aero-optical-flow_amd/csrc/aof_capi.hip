@@ -375,6 +375,7 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
             r.blocks = blocks1; r.subdirs = subdirs1;
             r.value_threshold = value_threshold_u16(p);
             r.tail = tail1; r.n_pairs = n_pairs;
+            r.chunk_parts = reinterpret_cast<uint32_t *>(ws + L.l1_hist);
             Timed t(ctx, AOF_K_REDUCE_L1, s);
             rc = launch_reduce(r, s);
             if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));
@@ -399,6 +400,7 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         r.blocks = blocks0; r.subdirs = subdirs0;
         r.value_threshold = value_threshold_u16(p);
         r.tail = tail0; r.n_pairs = n_pairs;
+        r.chunk_parts = reinterpret_cast<uint32_t *>(ws + L.l0_hist);
         Timed t(ctx, AOF_K_REDUCE, s);
         rc = launch_reduce(r, s);
         if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));

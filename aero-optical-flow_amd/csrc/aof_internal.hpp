@@ -32,6 +32,7 @@ bool tile8_geometry(const aof_params &p, int level);  // level can run the tile8
 int grid_for_level(const aof_params &p, int level, Grid *g);
 int level_range(const aof_params &p, int level);  // histogram half-range R
 int value_threshold_u16(const aof_params &p);     // SAD gate clamped to the u16 record
+int reduce_chunks(int nblocks);                   // 0: one reduction workgroup per pair reads all records
 
 // What turns a pair's vote histograms into its aof_flow (K3).
 struct FlowTail {
@@ -74,6 +75,7 @@ struct ReduceArgs {
     int64_t n_pairs;
     const uint32_t *parts;     // per-strip histograms written by the tile8 search (then blocks are not read)
     int32_t nstrips;
+    uint32_t *chunk_parts;     // large grids: scratch for per-chunk histograms ([n_pairs][chunks][2][bins]), or nullptr
 };
 
 struct PyramidArgs {

@@ -98,6 +98,14 @@ bool tile8_geometry(const aof_params &p, int level)
     return plan_tile8(w, g.nx, g.ny).rb > 0;
 }
 
+// K3 on grids beyond kReduceChunk*2 blocks runs in two steps: one workgroup per chunk of records
+// votes into a partial histogram, then the usual per-pair workgroup sums the chunks.
+int reduce_chunks(int nblocks)
+{
+    const int kReduceChunk = 4096;
+    return nblocks > 2 * kReduceChunk ? (nblocks + kReduceChunk - 1) / kReduceChunk : 0;
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace aof
@@ -234,6 +242,13 @@ int aof_workspace_layout(const aof_params *p, int64_t n_pairs, aof_ws_layout *ou
             const Tile8Plan pl = plan_tile8(p->width >> level, g.nx, g.ny);
             const size_t bins = 2 * (2 * (size_t)level_range(*p, level) + 1) + 1;
             bytes = n * (size_t)pl.nstrips * 2 * bins * sizeof(uint32_t);
+        }
+        {   // grids too large for one reduction workgroup per pair: per-chunk vote histograms
+            const Grid &g = level ? g1 : g0;
+            const size_t chunks = (size_t)reduce_chunks(g.blocks());
+            const size_t bins = 2 * (2 * (size_t)level_range(*p, level) + 1) + 1;
+            const size_t need = n * chunks * 2 * bins * sizeof(uint32_t);
+            if (need > bytes) bytes = need;
         }
         (level ? out->l1_hist : out->l0_hist) = off;
         off = align_up(off + bytes, 256);

@@ -111,11 +111,56 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
     if (tid == 0) finalise_flow(a.tail, pair, hist[0], hist[1], sums);
 }
 
+// Large grids (a 4K frame has 128 000 blocks): one workgroup per chunk of 4 096 records votes
+// into its own histogram; k_reduce then sums the chunks exactly like the strip kernel's votes.
+__global__ __launch_bounds__(kThreads) void k_reduce_chunk(ReduceArgs a, int chunks)
+{
+    __shared__ uint32_t hist[2][kMaxHist];
+    const int chunk = (int)(blockIdx.x % (uint32_t)chunks);
+    const int64_t pair = (int64_t)(blockIdx.x / (uint32_t)chunks);
+    const int tid = threadIdx.x;
+    const int centre = 2 * a.tail.range + 1, n = 2 * centre + 1;
+    for (int k = tid; k < n; k += kThreads) { hist[0][k] = 0; hist[1][k] = 0; }
+    __syncthreads();
+    const int per = (a.tail.nblocks + chunks - 1) / chunks;
+    const int b0 = chunk * per, b1 = min(a.tail.nblocks, b0 + per);
+    const uint32_t *blocks = reinterpret_cast<const uint32_t *>(a.blocks) + pair * a.tail.nblocks;
+    const uint8_t *subdirs = a.subdirs ? a.subdirs + pair * a.tail.nblocks : nullptr;
+    for (int base = b0; base < b1; base += kThreads) {  // uniform trip count: ballots need every lane
+        const int b = base + tid;
+        const bool in = b < b1;
+        const aof_block r = __builtin_bit_cast(aof_block, in ? blocks[b] : 0xFFFF0000u);
+        const int sd = in && subdirs ? subdirs[b] : 8;
+        const bool ok = in && !(r.sad == AOF_SAD_SKIPPED || (int)r.sad >= a.value_threshold);
+        int hx = 0, hy = 0;
+        if (ok && subdirs) {
+            hx = (sd == 0 || sd == 1 || sd == 7) ? 1 : ((sd == 3 || sd == 4 || sd == 5) ? -1 : 0);
+            hy = (sd == 1 || sd == 2 || sd == 3) ? 1 : ((sd == 5 || sd == 6 || sd == 7) ? -1 : 0);
+        }
+        wave_vote(hist[0], 2 * r.dx + hx + centre, ok);
+        wave_vote(hist[1], 2 * r.dy + hy + centre, ok);
+    }
+    __syncthreads();
+    uint32_t *out = a.chunk_parts + ((size_t)pair * chunks + chunk) * (size_t)(2 * n);
+    for (int k = tid; k < 2 * n; k += kThreads) out[k] = k < n ? hist[0][k] : hist[1][k - n];
+}
+
 }  // namespace
 
 int launch_reduce(const ReduceArgs &a, void *stream)
 {
     if (a.n_pairs == 0) return 0;
+    const int chunks = a.parts ? 0 : reduce_chunks(a.tail.nblocks);
+    if (chunks > 0 && a.chunk_parts && a.n_pairs * chunks <= 0x7FFFFFFF) {
+        hipLaunchKernelGGL(k_reduce_chunk, dim3((uint32_t)(a.n_pairs * chunks)), dim3(kThreads), 0,
+                           static_cast<hipStream_t>(stream), a, chunks);
+        ReduceArgs b = a;
+        b.parts = a.chunk_parts;
+        b.nstrips = chunks;
+        hipLaunchKernelGGL(k_reduce<kThreads>, dim3((uint32_t)a.n_pairs), dim3(kThreads), 0,
+                           static_cast<hipStream_t>(stream), b);
+        return (int)hipGetLastError();
+    }
     if (a.tail.nblocks <= 256 && !a.parts)  // sparse grids: one wave per pair
         hipLaunchKernelGGL(k_reduce<64>, dim3((uint32_t)((a.n_pairs + 3) / 4)), dim3(kThreads), 0,
                            static_cast<hipStream_t>(stream), a);

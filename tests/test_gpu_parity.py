@@ -489,6 +489,25 @@ def test_very_large_batch_of_small_frames(aof, orc, synth, gpu_device):
     check_against_oracle(aof, orc, p, prevs[idx], curs[idx], got, subdirs=outs[0][2][-m:])
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(subpixel=1, hist_filter=0), dict(pyramid_levels=2, mean_subtract=1)])
+def test_large_grid_two_step_reduction(aof, orc, synth, gpu_device, kw):
+    """1024x768 has 11 844 blocks per pair: the reduction runs as per-chunk vote histograms plus
+    the per-pair sum; records and flow records must still equal the oracle's."""
+    import torch
+    p = aof.default_params(1024, 768, **kw)
+    reach = 9 if p.pyramid_levels == 2 else 4
+    prevs, curs, _ = synth.make_batch(1024, 768, 3, reach, 1234, noise=5, brightness=4 if p.mean_subtract else 0)
+    prevs[2][:300] = 77                                   # a flat band: many skipped blocks
+    eng = aof.FlowEngine(p, 0)
+    assert eng.nblocks(0) > 8192
+    tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
+    sub = torch.full((3, eng.nblocks(0)), 99, dtype=torch.uint8, device=gpu_device) if p.subpixel else None
+    blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+    torch.cuda.synchronize()
+    check_against_oracle(aof, orc, p, prevs, curs, dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows)),
+                         subdirs=sub.cpu().numpy() if sub is not None else None)
+
+
 def test_empty_batch_and_errors(aof, gpu_device):
     import torch
     p = aof.default_params(128, 96)
