@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOF_LIB") or os.path.join(_HERE, "csrc", "libaof.so")
 
 GRID_DENSE, GRID_PX4FLOW = 0, 1
-SEARCH_EXHAUSTIVE, SEARCH_PRUNED, SEARCH_EXHAUSTIVE_STRIPS = 0, 1, 2
+SEARCH_EXHAUSTIVE, SEARCH_PRUNED, SEARCH_EXHAUSTIVE_STRIPS, SEARCH_PRUNED_STRIPS = 0, 1, 2, 3
 SAD_SKIPPED = 0xFFFF
 FLAG_FLOW_VALID, FLAG_PRED_VALID = 1, 2
 K_PYRAMID, K_SEARCH_L1, K_REDUCE_L1, K_SEARCH, K_REDUCE = range(5)

@@ -115,7 +115,7 @@ SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const
     a.blocks = blocks; a.subdirs = p.subpixel ? subdirs : nullptr;
     a.pred = pred; a.sums = sums; a.level = level; a.n_pairs = n;
     a.hist_parts = nullptr; a.hist_range = level_range(p, level);
-    a.prune = ctx->search_mode == AOF_SEARCH_PRUNED;
+    a.prune = ctx->search_mode == AOF_SEARCH_PRUNED || ctx->search_mode == AOF_SEARCH_PRUNED_STRIPS;
     return a;
 }
 
@@ -132,7 +132,7 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, uint32_t *parts
     // The LDS-strip kernel serves the pruned search and the explicit EXHAUSTIVE_STRIPS mode; the
     // default exhaustive search of 8x8 tiles runs lane-per-block straight from L2 (measured
     // faster on every dense configuration: full lane use, no staging phases, no barriers).
-    const bool strips = ctx->search_mode != AOF_SEARCH_EXHAUSTIVE;
+    const bool strips = ctx->search_mode == AOF_SEARCH_EXHAUSTIVE_STRIPS || ctx->search_mode == AOF_SEARCH_PRUNED_STRIPS;
     if (!ctx->force_generic && strips && tile8_supported(a)) {
         a.hist_parts = parts;   // the strips vote (half-pixel offsets included): K3 sums them
         *parts_used = parts;
@@ -225,7 +225,8 @@ const char *aof_search_variant(const aof_ctx *ctx)
     const aof_params &p = ctx->params;
     SearchArgs probe = search_args(ctx, 0, nullptr, nullptr, (int64_t)p.width * p.height, nullptr, nullptr,
                                    nullptr, nullptr, 1);
-    if (ctx->search_mode != AOF_SEARCH_EXHAUSTIVE && tile8_supported(probe)) return "tile8_lds";
+    const bool strips = ctx->search_mode == AOF_SEARCH_EXHAUSTIVE_STRIPS || ctx->search_mode == AOF_SEARCH_PRUNED_STRIPS;
+    if (strips && tile8_supported(probe)) return "tile8_lds";
     if (tile16_supported(probe)) return "tile16_lds";
     return lane8_supported(probe) ? "lane8" : "generic";
 }
@@ -239,8 +240,7 @@ int aof_set_force_generic(aof_ctx *ctx, int on)
 
 int aof_set_search_mode(aof_ctx *ctx, int mode)
 {
-    if (!ctx || (mode != AOF_SEARCH_EXHAUSTIVE && mode != AOF_SEARCH_PRUNED && mode != AOF_SEARCH_EXHAUSTIVE_STRIPS))
-        return -EINVAL;
+    if (!ctx || mode < AOF_SEARCH_EXHAUSTIVE || mode > AOF_SEARCH_PRUNED_STRIPS) return -EINVAL;
     if (mode != ctx->search_mode) {  // captured graphs hold the old kernel
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }

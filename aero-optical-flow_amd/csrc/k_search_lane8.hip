@@ -27,58 +27,32 @@ __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 }
 __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | lo; }
 
-// One block: record (and direction) written to global memory and returned for the votes.
-// Returns the half-pixel direction (8 = none).
-template <bool SUBPIXEL>
-__device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, int blk, int64_t item,
-                                            aof_block &rec)
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t x, uint32_t y)
 {
-    const int bx = blk % a.grid.nx, by = blk / a.grid.nx;
-    const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y;
-    const int W = a.w;
-    constexpr int m = SUBPIXEL ? 1 : 0;
-    int px = 0, py = 0;
-    if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
-    const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(a.w * a.h));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, x),
+                                                                  __builtin_bit_cast(ushort2_t, y)));
+}
 
-    rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
-    uint32_t *out = reinterpret_cast<uint32_t *>(a.blocks) + item;  // one dword store per record
-    // the search window (plus the half-pixel ring) must lie inside the frame
-    const int wx0 = i + px - 4, wy0 = j + py - 4;
-    if (wx0 - m < 0 || wy0 - m < 0 || wx0 + 16 + m > a.w || wy0 + 16 + m > a.h) {
-        *out = __builtin_bit_cast(uint32_t, rec);
-        if (SUBPIXEL) a.subdirs[item] = 8;
-        return 8;
-    }
-    const uint8_t *pr = a.prev + pair * a.pair_stride + (int64_t)j * W + i;
-    const uint8_t *pc = a.cur + pair * a.pair_stride + (int64_t)wy0 * W + wx0;
+// 4x4 gradient gate on tile bytes [2..5] x rows [2..5]
+__device__ __forceinline__ uint32_t gradient_gate(const uint32_t (&ref)[8][2])
+{
+    uint32_t mid[4], diff = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) mid[r] = __builtin_amdgcn_alignbyte(ref[r + 2][1], ref[r + 2][0], 2);
+#pragma unroll
+    for (int r = 0; r < 3; r++) diff = __builtin_amdgcn_sad_u8(mid[r], mid[r + 1], diff);
+#pragma unroll
+    for (int r = 0; r < 4; r++)  // bytes (3,4,5,5) against (2,3,4,5): the doubled byte adds 0
+        diff = __builtin_amdgcn_sad_u8(mid[r], __builtin_amdgcn_perm(0u, mid[r], 0x03030201u), diff);
+    return diff;
+}
 
-    uint32_t ref[8][2];
-    uint4 win[16];
-#pragma unroll
-    for (int r = 0; r < 8; r++) __builtin_memcpy(ref[r], pr + r * W, 8);
-#pragma unroll
-    for (int s = 0; s < 16; s++) __builtin_memcpy(&win[s], pc + s * W, 16);
-
-    // 4x4 gradient gate on tile bytes [2..5] x rows [2..5]
-    uint32_t diff = 0;
-    {
-        uint32_t mid[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) mid[r] = __builtin_amdgcn_alignbyte(ref[r + 2][1], ref[r + 2][0], 2);
-#pragma unroll
-        for (int r = 0; r < 3; r++) diff = __builtin_amdgcn_sad_u8(mid[r], mid[r + 1], diff);
-#pragma unroll
-        for (int r = 0; r < 4; r++)  // bytes (3,4,5,5) against (2,3,4,5): the doubled byte adds 0
-            diff = __builtin_amdgcn_sad_u8(mid[r], __builtin_amdgcn_perm(0u, mid[r], 0x03030201u), diff);
-    }
-    if (diff < (uint32_t)a.feature_threshold) {
-        *out = __builtin_bit_cast(uint32_t, rec);
-        if (SUBPIXEL) a.subdirs[item] = 8;
-        return 8;
-    }
-
-    // per dy: offsets 0..3 / 4..7 as packed u16, offset 8 as (sad << 16 | idx)
+// All 81 candidates: per dy, offsets 0..3 / 4..7 as packed u16, offset 8 as (sad << 16 | idx);
+// returns the smallest packed key = first minimum in scan order.
+template <bool EQUALISE>
+__device__ __forceinline__ uint32_t exhaustive_search(const uint4 (&win)[16], const uint32_t (&ref)[8][2], int delta)
+{
     u64 acc_lo[9], acc_hi[9];
     uint32_t acc_8[9];
 #pragma unroll
@@ -86,7 +60,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
 #pragma unroll
     for (int s = 0; s < 16; s++) {
         uint4 w = win[s];
-        if (delta != 0) w = sat_add_u8x16(w, delta);
+        if (EQUALISE && delta != 0) w = sat_add_u8x16(w, delta);
         const u64 p01 = pack64(w.x, w.y), p12 = pack64(w.y, w.z), p23 = pack64(w.z, w.w);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -113,6 +87,177 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
         best = min(best, min(min(k0, k1), k2));
         best = min(best, min(min(k3, k4), k5));
         best = min(best, min(min(k6, k7), acc_8[d]));
+    }
+    return best;
+}
+
+// One dy row (compile-time index D, so the window rows are plain registers) of the exact
+// pruned search: a partial SAD only grows, so when after two (then four) of the eight row pairs
+// no lane of the wave that still needs a result can beat or tie its best, the row is dropped for
+// the whole wave.  Returns false when the row was dropped.
+template <int D>
+__device__ __forceinline__ bool pruned_row(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+                                           uint32_t &best)
+{
+    u64 alo[2] = {0, 0}, ahi[2] = {0, 0};
+    uint32_t a8[2] = {(uint32_t)(D * 9 + 8), 0u};
+    auto row_pair = [&](int r, int set) {
+        const uint4 w = win[D + r];
+        const u64 p01 = pack64(w.x, w.y), p12 = pack64(w.y, w.z), p23 = pack64(w.z, w.w);
+        alo[set] = qsad(p01, ref[r][0], alo[set]);
+        ahi[set] = qsad(p12, ref[r][0], ahi[set]);
+        alo[set] = qsad(p12, ref[r][1], alo[set]);
+        ahi[set] = qsad(p23, ref[r][1], ahi[set]);
+        a8[set] = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], a8[set]);
+        a8[set] = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], a8[set]);
+    };
+    auto partial_min = [&]() -> uint32_t {  // <= 32 pixels per field: no carry between the u16 fields
+        const uint32_t s0 = (uint32_t)alo[0] + (uint32_t)alo[1], s1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
+        const uint32_t s2 = (uint32_t)ahi[0] + (uint32_t)ahi[1], s3 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
+        const uint32_t m = pk_min_u16(pk_min_u16(s0, s1), pk_min_u16(s2, s3));
+        return min(min(m & 0xFFFFu, m >> 16), (a8[0] + a8[1]) >> 16);
+    };
+    row_pair(0, 0);
+    row_pair(4, 1);
+    if (__ballot(need && partial_min() <= (best >> 16)) == 0) return false;
+    row_pair(2, 0);
+    row_pair(6, 1);
+    if (__ballot(need && partial_min() <= (best >> 16)) == 0) return false;
+    row_pair(1, 1);
+    row_pair(3, 0);
+    row_pair(5, 1);
+    row_pair(7, 0);
+    const uint32_t l0 = (uint32_t)alo[0] + (uint32_t)alo[1], l1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
+    const uint32_t h0 = (uint32_t)ahi[0] + (uint32_t)ahi[1], h1 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
+    const uint32_t base = (uint32_t)(D * 9);
+    const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
+    const uint32_t k2 = (l1 << 16) | (base + 2), k3 = (l1 & 0xFFFF0000u) | (base + 3);
+    const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
+    const uint32_t k6 = (h1 << 16) | (base + 6), k7 = (h1 & 0xFFFF0000u) | (base + 7);
+    best = min(best, min(min(k0, k1), k2));
+    best = min(best, min(min(k3, k4), k5));
+    best = min(best, min(min(k6, k7), a8[0] + a8[1]));
+    return true;
+}
+
+// The k-th row of the visiting order start, start-1, start+1, start-2, ... (whichever side is
+// still in range), closed form.
+constexpr int visit_order(int start, int k)
+{
+    if (k == 0) return start;
+    const int below = start, above = 8 - start;
+    const int pairs = below < above ? below : above;
+    if (k <= 2 * pairs) return (k & 1) ? start - (k + 1) / 2 : start + k / 2;
+    return below > above ? start - pairs - (k - 2 * pairs) : start + pairs + (k - 2 * pairs);
+}
+
+// All nine rows from a compile-time start row: straight-line code, every window row a plain
+// register (a run-time row index would push the 64-register window into scratch).
+template <int START, int K = 0>
+__device__ __forceinline__ int pruned_from(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+                                           uint32_t &best)
+{
+    const int dropped = pruned_row<visit_order(START, K)>(win, ref, need, best) ? 0 : 1;
+    if constexpr (K < 8) return dropped + pruned_from<START, K + 1>(win, ref, need, best);
+    else return dropped;
+}
+
+// The nine dy rows in the order start, start-1, start+1, ... (start is wave-uniform): one
+// specialised copy of the row sequence per start row; returns how many rows were dropped.
+__device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+                                             int start, uint32_t &best)
+{
+    switch (start) {
+    case 0: return pruned_from<0>(win, ref, need, best);
+    case 1: return pruned_from<1>(win, ref, need, best);
+    case 2: return pruned_from<2>(win, ref, need, best);
+    case 3: return pruned_from<3>(win, ref, need, best);
+    case 4: return pruned_from<4>(win, ref, need, best);
+    case 5: return pruned_from<5>(win, ref, need, best);
+    case 6: return pruned_from<6>(win, ref, need, best);
+    case 7: return pruned_from<7>(win, ref, need, best);
+    default: return pruned_from<8>(win, ref, need, best);
+    }
+}
+
+// One block: record (and direction) written to global memory and returned for the votes.
+// Returns the half-pixel direction (8 = none).  PRUNE: the wave-uniform exact pruned search;
+// start_row / prune_pays are the wave's hints carried from its previous chunk of blocks (every
+// lane of the wave stays in the control flow until the search is over, so ballots see them all).
+template <bool SUBPIXEL, bool PRUNE>
+__device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, int blk, int64_t item, bool live,
+                                            aof_block &rec, int &start_row, int &prune_pays)
+{
+    const int bx = blk % a.grid.nx, by = blk / a.grid.nx;
+    const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y;
+    const int W = a.w;
+    constexpr int m = SUBPIXEL ? 1 : 0;
+    int px = 0, py = 0, delta = 0;
+    if (live) {
+        if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
+        delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(a.w * a.h));
+    }
+    rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.blocks) + item;  // one dword store per record
+    // the search window (plus the half-pixel ring) must lie inside the frame
+    const int wx0 = i + px - 4, wy0 = j + py - 4;
+    const bool inside = live && !(wx0 - m < 0 || wy0 - m < 0 || wx0 + 16 + m > a.w || wy0 + 16 + m > a.h);
+    if (!PRUNE && !inside) {
+        if (live) {
+            *out = __builtin_bit_cast(uint32_t, rec);
+            if (SUBPIXEL) a.subdirs[item] = 8;
+        }
+        return 8;
+    }
+    const uint8_t *pr = a.prev + pair * a.pair_stride + (int64_t)j * W + i;
+    const uint8_t *pc = a.cur + pair * a.pair_stride + (int64_t)wy0 * W + wx0;
+
+    uint32_t ref[8][2];
+    uint4 win[16];
+    if (inside) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) __builtin_memcpy(ref[r], pr + r * W, 8);
+#pragma unroll
+        for (int s = 0; s < 16; s++) __builtin_memcpy(&win[s], pc + s * W, 16);
+    }
+    uint32_t gradient = 0;
+    if (inside) gradient = gradient_gate(ref);
+    const bool need = inside && gradient >= (uint32_t)a.feature_threshold;
+    if (!PRUNE && !need) {
+        *out = __builtin_bit_cast(uint32_t, rec);
+        if (SUBPIXEL) a.subdirs[item] = 8;
+        return 8;
+    }
+    if (PRUNE && need && delta != 0) {  // the pruned rows read a window row several times
+#pragma unroll
+        for (int s = 0; s < 16; s++) win[s] = sat_add_u8x16(win[s], delta);
+    }
+    uint32_t best = 0xFFFFFFFFu;
+    if constexpr (PRUNE) {
+        const unsigned long long needing = __ballot(need);
+        if (needing != 0) {
+            if (__builtin_amdgcn_readfirstlane(prune_pays) == 0) {
+                // noise-dominated images: the previous chunk of this wave could drop (almost)
+                // nothing, and the exhaustive code is the faster way to evaluate everything
+                if (need) best = exhaustive_search<false>(win, ref, 0);
+            } else {
+                const int start = __builtin_amdgcn_readfirstlane(start_row);
+                const int dropped = pruned_search(win, ref, need, start, best);
+                // the wave's next chunk starts where its first live block matched
+                const int src = __ffsll((long long)needing) - 1;
+                start_row = (int)((uint32_t)__shfl((int)best, src, 64) & 0xFFFFu) / 9;
+                prune_pays = dropped >= 2;
+            }
+        }
+        if (!need) {
+            if (live) {
+                *out = __builtin_bit_cast(uint32_t, rec);
+                if (SUBPIXEL) a.subdirs[item] = 8;
+            }
+            return 8;
+        }
+    } else {
+        best = exhaustive_search<true>(win, ref, delta);
     }
     const int idx = (int)(best & 0xFFFFu);
     rec.dx = (int8_t)(px + idx % 9 - 4);
@@ -153,19 +298,43 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
 }
 
 // Flat mapping: 256 consecutive (pair, block) items per workgroup; K3 follows.
-// Two to three waves per SIMD: the kernel trades occupancy for registers, so that a lane has
-// all 24 of its row loads in flight at once (one memory round trip per block instead of 16).
-template <bool SUBPIXEL>
-__global__ __launch_bounds__(kThreads, 4) void k_search_lane8(SearchArgs a, int64_t items, uint32_t total_wgs)
+// Four waves per SIMD (<= 128 VGPRs): a lane has all 24 of its row loads in flight at once and
+// the other three waves of the SIMD cover that round trip.
+// PRUNE: a workgroup walks `spw` consecutive 256-item chunks (block rows further down the same
+// frame) and each wave carries the dy row where its previous chunk matched.
+template <bool SUBPIXEL, bool PRUNE>
+__device__ __forceinline__ void search_chunks(const SearchArgs &a, int64_t items, uint32_t total_wgs, int spw)
 {
     // consecutive workgroups = consecutive block rows of one pair: keep them on one XCD, whose L2
     // then serves the search rows that vertically adjacent blocks share
-    const int64_t item = (int64_t)xcd_remap(blockIdx.x, total_wgs) * kThreads + threadIdx.x;
-    if (item >= items) return;
+    const int64_t wg = (int64_t)xcd_remap(blockIdx.x, total_wgs);
     const int nb = a.grid.blocks();
-    const int64_t pair = item / nb;
-    aof_block rec;
-    (void)search_block<SUBPIXEL>(a, pair, (int)(item - pair * nb), item, rec);
+    int start_row = 4, prune_pays = 1;
+    for (int c = 0; c < spw; c++) {
+        const int64_t item = (wg * spw + c) * kThreads + threadIdx.x;
+        const bool live = item < items;
+        if (!PRUNE && !live) return;
+        if (PRUNE && (item - threadIdx.x) >= items) return;   // whole workgroup past the end (uniform)
+        const int64_t pair = live ? item / nb : 0;
+        aof_block rec;
+        (void)search_block<SUBPIXEL, PRUNE>(a, pair, live ? (int)(item - pair * nb) : 0, item, live, rec, start_row,
+                                            prune_pays);
+    }
+}
+
+template <bool SUBPIXEL>
+__global__ __launch_bounds__(kThreads, 4) void k_search_lane8(SearchArgs a, int64_t items, uint32_t total_wgs, int spw)
+{
+    search_chunks<SUBPIXEL, false>(a, items, total_wgs, spw);
+}
+
+// The pruned search holds both code paths (pruned rows and the exhaustive fallback) and keeps
+// the whole window live across a data-dependent loop: three waves per SIMD (168 VGPRs).
+template <bool SUBPIXEL>
+__global__ __launch_bounds__(kThreads, 3) void k_search_lane8_pruned(SearchArgs a, int64_t items, uint32_t total_wgs,
+                                                                      int spw)
+{
+    search_chunks<SUBPIXEL, true>(a, items, total_wgs, spw);
 }
 
 // Grouped mapping for grids of a few dozen blocks (the published sparse grid): a workgroup owns
@@ -186,7 +355,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_flow_lane8(SearchArgs a, FlowTa
     aof_block rec;
     rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
     int subdir = 8;
-    if (live) subdir = search_block<SUBPIXEL>(a, pair0 + p, blk, (pair0 + p) * nb + blk, rec);
+    int start_row = 4, prune_pays = 1;  // (unused: the grouped kernel always searches exhaustively)
+    if (live) subdir = search_block<SUBPIXEL, false>(a, pair0 + p, blk, (pair0 + p) * nb + blk, true, rec, start_row,
+                                                     prune_pays);
     const bool ok = live && (uint32_t)rec.sad < (uint32_t)a.value_threshold;  // skipped = 0xFFFF
     const int hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
     const int hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
@@ -217,12 +388,20 @@ bool lane8_supported(const SearchArgs &a)
 int launch_search_lane8(const SearchArgs &a, void *stream)
 {
     if (a.n_pairs == 0) return 0;
-    const int64_t items = a.n_pairs * a.grid.blocks();
-    const int64_t wgs = (items + kThreads - 1) / kThreads;
-    if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     if (a.subpixel && !a.subdirs) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(a.subpixel ? k_search_lane8<true> : k_search_lane8<false>, dim3((uint32_t)wgs),
-                       dim3(kThreads), 0, static_cast<hipStream_t>(stream), a, items, (uint32_t)wgs);
+    const int64_t items = a.n_pairs * a.grid.blocks();
+    const int64_t chunks = (items + kThreads - 1) / kThreads;
+    // pruned search: consecutive chunks per workgroup so that all but the first inherit a start
+    // row; fewer when the launch is small and needs the workgroups for parallelism
+    int spw = 1;
+    if (a.prune) spw = chunks >= 4 * 4096 ? 4 : (chunks >= 2 * 4096 ? 2 : 1);
+    const int64_t wgs = (chunks + spw - 1) / spw;
+    if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
+    void (*fn)(SearchArgs, int64_t, uint32_t, int);
+    if (a.prune) fn = a.subpixel ? k_search_lane8_pruned<true> : k_search_lane8_pruned<false>;
+    else fn = a.subpixel ? k_search_lane8<true> : k_search_lane8<false>;
+    hipLaunchKernelGGL(fn, dim3((uint32_t)wgs), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a, items,
+                       (uint32_t)wgs, spw);
     return (int)hipGetLastError();
 }
 

@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
-    ap.add_argument("--search", default="exhaustive", choices=["exhaustive", "pruned", "strips"],
+    ap.add_argument("--search", default="exhaustive", choices=["exhaustive", "pruned", "strips", "pruned_strips"],
                     help="exhaustive (default, the data-independent rate the metric is quoted on) or "
                          "pruned: exact partial-distortion elimination, same records, rate depends on "
                          "the images (fast on these clean synthetic translations)")
@@ -273,6 +273,8 @@ def main():
         eng.set_search_mode(aof.SEARCH_PRUNED)
     elif args.search == "strips":
         eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
+    elif args.search == "pruned_strips":
+        eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
     if args.force_generic:
         eng.force_generic(True)
     if args.scaling == "strong":
@@ -388,15 +390,13 @@ def main():
                      "algorithmic_bytes_per_pair": alg_bytes, "pairs_per_launch": n,
                      # nominal abs-diffs of the exhaustive scan; meaningless when candidates are pruned
                      "abs_diff_per_s": round(aof.abs_diffs(p) * n / (k2_ms * 1e-3), 1)
-                     if args.search != "pruned" else None},
+                     if not args.search.startswith("pruned") else None},
         "kernels_ms": per_kernel,
     }
 
     # ---- secondary, clearly separate: the opt-in exact-pruning search on the same batch ----
     # (same records bit for bit; data-dependent rate, so never the headline `value`)
-    eng.set_search_mode(aof.SEARCH_PRUNED)
-    pruned_available = eng.variant == "tile8_lds"
-    eng.set_search_mode(aof.SEARCH_EXHAUSTIVE)
+    pruned_available = eng.variant == "lane8"
     if args.search == "exhaustive" and pruned_available and not args.force_generic:
         ref_blocks = blocks.clone()
         eng.set_search_mode(aof.SEARCH_PRUNED)
@@ -416,7 +416,7 @@ def main():
             "per_gpu_value": round(n * args.steps / dt, 1), "unit": "frame-pairs/s", "kernel_ms": round(pk2, 5),
             "roofline_frac": round(alg_bytes * n / (pk2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "records_identical_to_exhaustive": bool(torch.equal(ref_blocks, blocks)),
-            "note": "opt-in AOF_SEARCH_PRUNED (partial-distortion elimination, LDS-strip kernel): bit-identical records, "
+            "note": "opt-in AOF_SEARCH_PRUNED (partial-distortion elimination): bit-identical records, "
                     "rate depends on the images; not the headline"}
         state["i"] = 1  # flows2[0] holds the latest records
 

@@ -128,7 +128,7 @@ int aof_set_force_generic(aof_ctx *ctx, int on);
  * EXHAUSTIVE (default): all 81 candidates of every block are summed completely -- a
  *   data-independent rate, the one BASELINE's metric is quoted on.  The library picks the
  *   fastest kernel for the configuration (lane-per-block from L2 for 8x8 tiles).
- * PRUNED: exact partial-distortion elimination in the LDS-strip kernel.  The nine dy rows are
+ * PRUNED: exact partial-distortion elimination.  The nine dy rows are
  *   visited outwards from dy = 0; after two of a row's eight row pairs a wave drops the row
  *   when no lane's partial SAD can still beat its best (a partial sum only grows).  The rate
  *   then depends on the images: fast when blocks have a clear match near the centre, slower
@@ -138,6 +138,7 @@ int aof_set_force_generic(aof_ctx *ctx, int on);
 #define AOF_SEARCH_EXHAUSTIVE 0
 #define AOF_SEARCH_PRUNED 1
 #define AOF_SEARCH_EXHAUSTIVE_STRIPS 2
+#define AOF_SEARCH_PRUNED_STRIPS 3 /* the pruned search in the LDS-strip kernel (comparison) */
 int aof_set_search_mode(aof_ctx *ctx, int mode);
 
 /* ---- the hot path, device-resident (batched) ----

@@ -226,7 +226,7 @@ def test_shapes_and_options(aof, orc, synth, gpu_device, case):
                          subdirs=sub.cpu().numpy() if sub is not None else None)
 
 
-@pytest.mark.parametrize("mode", ["exhaustive", "strips", "pruned", "generic"])
+@pytest.mark.parametrize("mode", ["exhaustive", "strips", "pruned", "pruned_strips", "generic"])
 @pytest.mark.parametrize("kw", [dict(), dict(pyramid_levels=2, mean_subtract=1)])
 def test_vga_dense_half_pixel(aof, orc, synth, gpu_device, mode, kw):
     """Dense grid with half-pixel refinement (origin S+1): the LDS-tiled integer search on the
@@ -243,6 +243,9 @@ def test_vga_dense_half_pixel(aof, orc, synth, gpu_device, mode, kw):
         eng.force_generic(True)
     elif mode == "pruned":
         eng.set_search_mode(aof.SEARCH_PRUNED)
+        assert eng.variant == "lane8"
+    elif mode == "pruned_strips":
+        eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
         assert eng.variant == "tile8_lds"
     elif mode == "strips":
         eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
@@ -332,9 +335,11 @@ def test_no_writes_outside_the_output_buffers(aof, synth, gpu_device, case):
         gaps.append((off + v, end + guard))
         off = end + guard
     assert views["ws"].data_ptr() % 256 == 0 and views["blocks"].data_ptr() % 4 == 0
-    for mode in ("default", "strips", "pruned"):
+    for mode in ("default", "strips", "pruned", "pruned_strips"):
         if mode == "pruned":
             eng.set_search_mode(aof.SEARCH_PRUNED)
+        elif mode == "pruned_strips":
+            eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
         elif mode == "strips":
             eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
         eng.flow_batch(tp, tc, blocks=views["blocks"].view(torch.int32).view(n, nb),

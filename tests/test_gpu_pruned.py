@@ -14,8 +14,7 @@ def run(aof, p, prevs, curs, device, mode, hint_fill=None, reps=1):
     eng = aof.FlowEngine(p, 0)
     # the strip kernel serves PRUNED and EXHAUSTIVE_STRIPS; plain EXHAUSTIVE requests become the
     # latter here so that both code paths of that kernel are compared
-    eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS if mode == aof.SEARCH_EXHAUSTIVE else mode)
-    assert eng.variant == "tile8_lds"
+    eng.set_search_mode(mode)
     tp, tc = torch.from_numpy(prevs).to(device), torch.from_numpy(curs).to(device)
     n = prevs.shape[0]
     L = aof.workspace_layout(p, n)
@@ -31,9 +30,12 @@ def run(aof, p, prevs, curs, device, mode, hint_fill=None, reps=1):
 def both_modes_match_oracle(aof, orc, p, prevs, curs, device):
     po = orc.params_from(p)
     refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(prevs.shape[0])]
-    for mode, hint, reps in ((aof.SEARCH_EXHAUSTIVE, None, 1), (aof.SEARCH_PRUNED, None, 1),
-                             (aof.SEARCH_PRUNED, 0, 1), (aof.SEARCH_PRUNED, 8, 2),
-                             (aof.SEARCH_PRUNED, -12345, 1), (aof.SEARCH_PRUNED, 77, 3)):
+    # every search mode: default (lane-per-block), pruned in both kernels, exhaustive strips
+    for mode, hint, reps in ((aof.SEARCH_EXHAUSTIVE, None, 1), (aof.SEARCH_EXHAUSTIVE_STRIPS, None, 1),
+                             (aof.SEARCH_PRUNED, None, 1), (aof.SEARCH_PRUNED, 0, 2),
+                             (aof.SEARCH_PRUNED_STRIPS, None, 1), (aof.SEARCH_PRUNED_STRIPS, 0, 1),
+                             (aof.SEARCH_PRUNED_STRIPS, 8, 2), (aof.SEARCH_PRUNED_STRIPS, -12345, 1),
+                             (aof.SEARCH_PRUNED_STRIPS, 77, 3)):
         b, f = run(aof, p, prevs, curs, device, mode, hint, reps)
         for i, r in enumerate(refs):
             assert b[i].tobytes() == r["blocks"].tobytes(), (mode, hint, i)

@@ -78,7 +78,7 @@ def main():
         po = orc.params_from(p)
         refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
         tp, tc = torch.from_numpy(prevs).to(dev), torch.from_numpy(curs).to(dev)
-        for mode in ("exhaustive", "strips", "pruned", "generic"):
+        for mode in ("exhaustive", "strips", "pruned", "pruned_strips", "generic"):
             eng = aof.FlowEngine(p, 0)
             if mode == "generic":
                 eng.force_generic(True)
@@ -86,6 +86,8 @@ def main():
                 eng.set_search_mode(aof.SEARCH_PRUNED)
             elif mode == "strips":
                 eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
+            elif mode == "pruned_strips":
+                eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
             nb = eng.nblocks(0)
             sub = torch.full((n, nb), 99, dtype=torch.uint8, device=dev) if p.subpixel else None
             blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
@@ -103,7 +105,7 @@ def main():
         done += 1
         if done % 25 == 0:
             print(f"{done} cases ok ({time.time() - t0:.0f} s), skipped {skipped}, kernels {variants}", flush=True)
-    print(f"fuzz passed: {done} cases x 4 device paths, {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
+    print(f"fuzz passed: {done} cases x 5 device paths, {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
