@@ -396,7 +396,7 @@ def main():
 
     # ---- secondary, clearly separate: the opt-in exact-pruning search on the same batch ----
     # (same records bit for bit; data-dependent rate, so never the headline `value`)
-    pruned_available = eng.variant == "lane8"
+    pruned_available = eng.variant == "lane8" and eng.nblocks(0) > 256  # (the grouped small-grid kernel never prunes)
     if args.search == "exhaustive" and pruned_available and not args.force_generic:
         ref_blocks = blocks.clone()
         eng.set_search_mode(aof.SEARCH_PRUNED)

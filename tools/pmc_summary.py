@@ -47,7 +47,7 @@ def main():
     # the level-0 search is the k_search kernel that moves the most bytes
     # (bench.py also runs the opt-in pruned search, template argument PRUNE = true: not the headline)
     names = [k for k in traffic if k.startswith("k_search") or k.startswith("k_flow")]
-    names = [k for k in names if not k.endswith(", true>")] or names
+    names = [k for k in names if not k.endswith(", true>") and "_pruned" not in k] or names
     search = sorted(names, key=lambda k: -sum(traffic[k]))
     if search:
         rd, wr = traffic[search[0]]
