@@ -1,15 +1,29 @@
-// K2 (lane8) -- 8x8 SAD search over +-4 px for ANY grid, frame width and predictor: the
-// published sparse PX4Flow grid (BASELINE configs[0]) and dense grids whose rows are not a
-// multiple of 16 bytes, which the LDS-strip kernel cannot stage (DESIGN.md "Kernels").
+// K2 (lane8) -- the dominant kernel: 8x8 SAD search over +-4 px on ANY grid, frame width and
+// predictor (DESIGN.md "Spec": Search; "Kernels": K2).  The dense grids of BASELINE configs[1..3]
+// as well as the published sparse PX4Flow grid of configs[0].
 //
-// One LANE per block, 256 consecutive (pair, block) items per workgroup, no LDS: a sparse grid
-// touches each pixel about once, so there is nothing for LDS to share.  A lane reads its 8x8
-// reference tile (8 unaligned 8-byte loads) and its 16 search rows (16 unaligned 16-byte
-// loads) straight from global memory -- small frames stay in L2, e.g. a 64x64 pair is 8 KB --
-// and runs the same arithmetic as k_search_tile8: per (search row, reference row) four
-// v_qsad_pk_u16_u8 and two v_sad_hi_u8, packed u16 accumulators, per-lane v_min3 arg-min over
-// (sad << 16 | idx) = first minimum in scan order.  Half-pixel refinement, when enabled,
-// follows in the same lane from the ring of the best match (aof_refine.hpp).
+// One LANE per block, 256 consecutive (pair, block) items per workgroup, no LDS, no barriers.  A
+// lane reads its 8x8 reference tile (8 unaligned 8-byte loads) and its 16 search rows (16
+// unaligned 16-byte loads) straight from global memory, all issued before the first use, and
+// evaluates all 81 candidates with v_qsad_pk_u16_u8 -- four horizontally sliding 4-byte SADs
+// per instruction, packed u16 accumulators (max 64*255 = 16320 fits) -- plus v_sad_hi_u8 for
+// the ninth column, which accumulates straight into the high half of a register pre-loaded
+// with the candidate index.  No cross-lane traffic: the arg-min is a per-lane v_min3_u32 tree
+// over the packed keys (sad << 16 | idx), i.e. "first minimum in scan order wins".  Half-pixel
+// refinement, when enabled, follows in the same lane from the ring of the best match
+// (aof_refine.hpp).
+//
+// Why no LDS staging: on a dense grid neighbouring lanes read neighbouring 8-byte columns, so
+// a wave's row load is one contiguous run; vertically adjacent blocks share half their rows
+// through L1/L2 (workgroup ids are remapped so that consecutive block rows of a pair stay on one
+// XCD); HBM sees every frame byte once (PMC: 624 MB read per 629 MB of frames).  Against the
+// LDS-strip kernel (k_search_tile8, this round's first dominant kernel) all 64 lanes of every
+// wave work, nothing waits at a barrier and there is no staging phase to hide: 8 % faster on
+// C2, 16 % with half-pixel refinement (profiles/r01_p_lane8_vs_strips.txt).
+//
+// Variants: k_search_lane8 (flat items, K3 follows), k_flow_lane8 (grids of 8..256 blocks: a
+// workgroup owns whole pairs and finalises their flow records itself), k_search_lane8_pruned
+// (AOF_SEARCH_PRUNED: exact partial-distortion elimination, see pruned_row below).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 #include "aof_reduce.hpp"
