@@ -1,5 +1,8 @@
-// K2 (tile8) -- the dominant kernel: 8x8 SAD search over +-4 px on a dense grid
-// (DESIGN.md "Spec": Search; "Kernels": K2).
+// K2 (tile8) -- 8x8 SAD search over +-4 px on a dense grid from LDS-staged strips
+// (DESIGN.md "Spec": Search; "Kernels": K2).  This round's first dominant kernel; since
+// k_search_lane8 (no LDS, rows straight from L2) measured 8-16 % faster on the same
+// configurations it serves the comparison modes AOF_SEARCH_EXHAUSTIVE_STRIPS and
+// AOF_SEARCH_PRUNED_STRIPS only.
 //
 // Mapping.  A workgroup owns a strip of `rb` block rows of one frame pair and
 // stages the strip's pixels ONCE into LDS as two flat, fully coalesced 16-byte
