@@ -10,9 +10,9 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for wl in c2 c3 c5 c2h c1b; do
     extra=""; [ $wl = c5 ] && extra="--pairs 256"; [ $wl = c1b ] && extra="--pairs 65536"
-    timeout -k 10 300 python3 $R/bench.py --workload $wl $extra --steps 50 --warmup 5 > $O/bench_$wl.json 2> $O/bench_$wl.err || { echo "bench $wl failed"; exit 1; }
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$wl -- python3 $R/bench.py --workload $wl $extra --steps 20 --warmup 3 --cpu-seconds 0 > $O/kt_$wl.log 2>&1 || { echo "kernel trace $wl failed"; exit 1; }
-    python3 $R/tools/summarize_rocprof.py $(ls $O/kt_$wl/*/*kernel_stats.csv | head -1) "bench.py --workload $wl $extra --steps 20 --warmup 3" > $O/kernel_stats_$wl.txt
+    timeout -k 10 300 python3 $R/bench.py --workload $wl $extra > $O/bench_$wl.json 2> $O/bench_$wl.err || { echo "bench $wl failed"; exit 1; }
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$wl -- python3 $R/bench.py --workload $wl $extra --cpu-seconds 0 > $O/kt_$wl.log 2>&1 || { echo "kernel trace $wl failed"; exit 1; }
+    python3 $R/tools/summarize_rocprof.py $(ls $O/kt_$wl/*/*kernel_stats.csv | head -1) "bench.py --workload $wl $extra --cpu-seconds 0 (200 steps)" > $O/kernel_stats_$wl.txt
     rm -rf $O/kt_$wl
     echo "$wl done"
 done
