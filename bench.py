@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-steps", type=int, default=500,
+                    help="untimed steps before the warm-up steps (clock settling under sustained load); 0 = off")
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
@@ -330,6 +332,16 @@ def main():
     # HIP events around the dominant kernel (K2, level 0) of every launch, on the launch stream;
     # the other kernels are timed in a few extra steps after the timed region, because every
     # event pair costs the stream a few microseconds of serialisation
+    # Untimed settling phase before the W warm-up steps: the device's clocks take tens of
+    # milliseconds of sustained load to settle (measured: K2 0.251 ms in a cold 20-step run,
+    # 0.227 ms after 150 ms of load), and W is often only a handful of steps.  A fixed number of
+    # steps, so that every rank issues the same collectives.
+    for i in range(args.settle_steps):
+        step()
+        if i % 50 == 49:
+            drain()
+            torch.cuda.synchronize(device)
+    fence()
     eng.set_profiling(True, kernels=[aof.K_SEARCH])
     for _ in range(args.warmup):
         step()

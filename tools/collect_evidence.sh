@@ -20,7 +20,7 @@ for wl in c2 c3 c5 c2h c1b; do
     extra=""; pairs=1024; [ $wl = c5 ] && extra="--pairs 256" && pairs=256; [ $wl = c1b ] && extra="--pairs 65536" && pairs=65536
     for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"; do
         tag=$(echo $set | cut -d" " -f1)
-        timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$wl/$tag -- python3 $R/bench.py --workload $wl $extra --steps 5 --warmup 2 --cpu-seconds 0 > $O/pmc_${wl}_$tag.log 2>&1 || { echo "pmc $wl $tag failed"; exit 1; }
+        timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$wl/$tag -- python3 $R/bench.py --workload $wl $extra --steps 5 --warmup 2 --settle-steps 0 --cpu-seconds 0 > $O/pmc_${wl}_$tag.log 2>&1 || { echo "pmc $wl $tag failed"; exit 1; }
     done
     python3 $R/tools/pmc_summary.py $O/pmc_$wl $wl $pairs $O/pmc_$wl.txt > /dev/null
     rm -rf $O/pmc_$wl
