@@ -45,6 +45,8 @@ struct aof_ctx {
     // streaming entry point as two captured hipGraphs (one per ping-pong slot):
     // H2D of the pinned frame -> kernels -> D2H of the 16-byte result, one launch per call
     uint8_t *h_frame;           // pinned staging copy of the caller's frame
+    uint8_t *h_frames[2];       // small frames: pinned ping-pong frames the kernels read in place
+    bool zero_copy;             // (no H2D copy: a 64x64 frame is 4 KB over PCIe)
     aof_flow *h_flow;           // pinned result
     hipGraphExec_t push_graph[2];
     bool graph_disabled;        // capture failed once: stay on the plain path
@@ -198,6 +200,7 @@ void aof_destroy(aof_ctx *ctx)
     for (int i = 0; i < 2; i++) if (ctx->push_graph[i]) (void)hipGraphExecDestroy(ctx->push_graph[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->h_frame) (void)hipHostFree(ctx->h_frame);
+    for (int i = 0; i < 2; i++) if (ctx->h_frames[i]) (void)hipHostFree(ctx->h_frames[i]);
     if (ctx->h_flow) (void)hipHostFree(ctx->h_flow);
     for (int i = 0; i < 2; i++) if (ctx->d_frames[i]) (void)hipFree(ctx->d_frames[i]);
     for (int i = 0; i < 2; i++) if (ctx->d_pair[i]) (void)hipFree(ctx->d_pair[i]);
@@ -452,6 +455,13 @@ static int ensure_host_state(aof_ctx *ctx)
     ctx->ws_bytes = L.total_bytes;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_flow, sizeof(aof_flow)));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_frame, frame, hipHostMallocDefault));
+    // Frames of up to 64 KB (the reference's 64x64 .. 128x128 images) are not copied to the device
+    // at all: the kernels read the pinned host copies over PCIe, which takes less time than the
+    // copy node it replaces.  Larger frames keep the H2D copy and the device-resident previous frame.
+    ctx->zero_copy = frame <= 64 * 1024;
+    if (ctx->zero_copy)
+        for (int i = 0; i < 2; i++)
+            HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_frames[i], frame, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_flow, sizeof(aof_flow), hipHostMallocMapped | hipHostMallocCoherent));
     return 0;
 }
@@ -469,10 +479,12 @@ static void build_push_graph(aof_ctx *ctx, int slot)
         return;
     }
     ctx->capturing = true;
-    bool ok = hipMemcpyAsync(ctx->d_frames[slot], ctx->h_frame, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    uint8_t *const *frames = ctx->zero_copy ? ctx->h_frames : ctx->d_frames;
+    bool ok = ctx->zero_copy ||
+              hipMemcpyAsync(ctx->d_frames[slot], ctx->h_frame, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
     // K3 writes the 16-byte result straight into the pinned (device-visible, coherent) host
     // record: no D2H copy node; it is visible to the host once the stream has drained.
-    ok = ok && aof_flow_batch_device(ctx, ctx->d_frames[1 - slot], ctx->d_frames[slot], (int64_t)bytes, 1,
+    ok = ok && aof_flow_batch_device(ctx, frames[1 - slot], frames[slot], (int64_t)bytes, 1,
                                      ctx->d_blocks, ctx->d_subdirs, ctx->h_flow, ctx->d_ws, ctx->ws_bytes,
                                      ctx->stream) == 0;
     ctx->capturing = false;
@@ -540,7 +552,9 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
         if (!ctx->push_graph[slot]) build_push_graph(ctx, slot);
         if (ctx->push_graph[slot]) return stream_push_graph(ctx, frame, flow, slot);
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[slot], frame, bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t *const *frames = ctx->zero_copy ? ctx->h_frames : ctx->d_frames;
+    if (ctx->zero_copy) std::memcpy(ctx->h_frames[slot], frame, bytes);
+    else HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[slot], frame, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->have_prev) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may free `frame` on return
         ctx->cur_slot = slot;
@@ -548,7 +562,7 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
         std::memset(flow, 0, sizeof(*flow));
         return 1;
     }
-    rc = run_one(ctx, ctx->d_frames[ctx->cur_slot], ctx->d_frames[slot], nullptr, nullptr, flow);
+    rc = run_one(ctx, frames[ctx->cur_slot], frames[slot], nullptr, nullptr, flow);
     ctx->cur_slot = slot;
     return rc;
 }
@@ -556,7 +570,8 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
 // Same contract as the plain path above, one hipGraphLaunch per frame.
 static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow, int slot)
 {
-    std::memcpy(ctx->h_frame, frame, (size_t)ctx->params.width * ctx->params.height);
+    std::memcpy(ctx->zero_copy ? ctx->h_frames[slot] : ctx->h_frame, frame,
+                (size_t)ctx->params.width * ctx->params.height);
     HIP_TRY(ctx, hipGraphLaunch(ctx->push_graph[slot], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *flow = *ctx->h_flow;
