@@ -44,8 +44,12 @@ __global__ __launch_bounds__(kThreads) void k_pyramid_vec(PyramidArgs a, int row
     uint32_t sum0 = 0, sum1 = 0;
     for (int it = threadIdx.x; it < items; it += kThreads) {
         const int y1 = y_begin + it / chunks, c = it % chunks;
-        const uint4 r0 = *reinterpret_cast<const uint4 *>(src + (int64_t)(2 * y1) * a.w + c * 16);
-        const uint4 r1 = *reinterpret_cast<const uint4 *>(src + (int64_t)(2 * y1 + 1) * a.w + c * 16);
+        // streamed once: non-temporal loads keep the frames from pushing the level-1 frames this
+        // kernel writes (and the next kernel reads) out of L2 / the memory-side cache (K1 -10 %)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + (int64_t)(2 * y1) * a.w + c * 16));
+        const u32x4 q1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + (int64_t)(2 * y1 + 1) * a.w + c * 16));
+        const uint4 r0 = make_uint4(q0.x, q0.y, q0.z, q0.w), r1 = make_uint4(q1.x, q1.y, q1.z, q1.w);
         sum0 = byte_sum(r0.x, sum0); sum0 = byte_sum(r0.y, sum0);
         sum0 = byte_sum(r0.z, sum0); sum0 = byte_sum(r0.w, sum0);
         sum0 = byte_sum(r1.x, sum0); sum0 = byte_sum(r1.y, sum0);
