@@ -22,7 +22,7 @@ namespace aof {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kRowsPerBlock = 32;
+constexpr int kRowsPerBlock = 128;
 constexpr int kField = 12;  // bits per packed counter
 
 __device__ __forceinline__ int exposure_bin(uint32_t v) { return (int)((v * 10u) / 255u); }  // 10 => dropped
@@ -72,29 +72,42 @@ __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const 
 
     if (vec) {  // crop_w % 16 == 0: one 16-byte piece per lane
         const int pieces = p.crop_width / 16, items = (row_end - row_begin) * pieces;
+        // four pieces per lane and trip, all four loads in flight before the first is used (the
+        // kernel moves 32 KB per frame and lives on memory-level parallelism)
+        constexpr int kUnroll = 4;
         int round = 0;
-        for (int base = 0; base < items; base += kThreads, round++) {  // uniform trip count
-            const int it = base + tid;
-            const bool active = it < items;
-            const int y = row_begin + (active ? it / pieces : 0), x = active ? (it % pieces) * 16 : 0;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (active) {
-                __builtin_memcpy(&v, src + (int64_t)y * p.camera_width + x, 16);  // window start may be unaligned
-                if (dst) *reinterpret_cast<uint4 *>(dst + (int64_t)y * p.crop_width + x) = v;
-            }
-            if (active && hist && y >= my0 && y < my1 && x + 16 > mx0 && x < mx1) {
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int base = 0; base < items; base += kUnroll * kThreads) {  // uniform trip count
+            uint4 v[kUnroll];
+            int ys[kUnroll], xs[kUnroll];
+            bool act[kUnroll];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const bool in = x + k >= mx0 && x + k < mx1;
-                    const int b = exposure_bin((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-                    // b == 10 (v == 255) is outside cv::calcHist's range: shifted out of both words
-                    cnt_lo += (in && b < 5) ? 1ull << (kField * b) : 0ull;
-                    cnt_hi += (in && b >= 5 && b < 10) ? 1ull << (kField * (b - 5)) : 0ull;
-                }
+            for (int u = 0; u < kUnroll; u++) {
+                const int it = base + u * kThreads + tid;
+                act[u] = it < items;
+                ys[u] = row_begin + (act[u] ? it / pieces : 0);
+                xs[u] = act[u] ? (it % pieces) * 16 : 0;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (act[u]) __builtin_memcpy(&v[u], src + (int64_t)ys[u] * p.camera_width + xs[u], 16);  // window start may be unaligned
             }
-            // 3 pieces x 16 pixels x 64 lanes = 3072 < 4096: flush before a field can overflow
-            if (hist && round % 3 == 2) { flush_counts(s_hist, cnt_lo, cnt_hi); cnt_lo = cnt_hi = 0; }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++, round++) {
+                const int y = ys[u], x = xs[u];
+                const bool active = act[u];
+                if (active && dst) *reinterpret_cast<uint4 *>(dst + (int64_t)y * p.crop_width + x) = v[u];
+                if (active && hist && y >= my0 && y < my1 && x + 16 > mx0 && x < mx1) {
+                    const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const bool in = x + k >= mx0 && x + k < mx1;
+                        const int b = exposure_bin((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                        // b == 10 (v == 255) is outside cv::calcHist's range: shifted out of both words
+                        cnt_lo += (in && b < 5) ? 1ull << (kField * b) : 0ull;
+                        cnt_hi += (in && b >= 5 && b < 10) ? 1ull << (kField * (b - 5)) : 0ull;
+                    }
+                }
+                // 3 pieces x 16 pixels x 64 lanes = 3072 < 4096: flush before a field can overflow
+                if (hist && round % 3 == 2) { flush_counts(s_hist, cnt_lo, cnt_hi); cnt_lo = cnt_hi = 0; }
+            }
         }
         if (hist) flush_counts(s_hist, cnt_lo, cnt_hi);
     } else {
