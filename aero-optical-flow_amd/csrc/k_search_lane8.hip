@@ -208,8 +208,24 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
     constexpr int m = SUBPIXEL ? 1 : 0;
     int px = 0, py = 0, delta = 0;
     if (live) {
-        if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
-        delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(a.w * a.h));
+        // Per-pair inputs (predictor, pixel sums).  Almost every wave lies inside one pair: fetch
+        // them for the wave's first pair through a wave-uniform address (scalar loads, served by
+        // the constant cache) and only the lanes of a following pair through their own -- a
+        // per-lane load here is a full memory round trip in front of the 24 row loads.
+        const int64_t first = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pair >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pair);
+        typedef const __attribute__((address_space(4))) uint32_t *const_u32;  // read-only during the kernel
+        if (a.pred) {
+            const uint32_t w3 = ((const_u32)(a.pred + first))[3];  // quality, flags, pred_x, pred_y
+            px = (int8_t)(w3 >> 16); py = (int8_t)(w3 >> 24);
+            if (pair != first) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
+        }
+        if (a.sums) {
+            const uint32_t npix = (uint32_t)(a.w * a.h);
+            const const_u32 sm = (const_u32)(a.sums + first * 4);
+            delta = (int)((sm[a.level] + npix / 2) / npix) - (int)((sm[2 + a.level] + npix / 2) / npix);
+            if (pair != first) delta = equalise_delta(a.sums, pair, a.level, npix);
+        }
     }
     rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
     uint32_t *out = reinterpret_cast<uint32_t *>(a.blocks) + item;  // one dword store per record

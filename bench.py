@@ -35,6 +35,8 @@ WORKLOADS = {
            640, 480, dict(), 4),
     "c3": ("C3 640x480, 2-level mean-subtracted pyramid + 4x4 gate/histogram filter",
            640, 480, dict(pyramid_levels=2, mean_subtract=1), 9),
+    "c3n": ("C3 without the mean equalisation (pyramid + predictor only)",
+            640, 480, dict(pyramid_levels=2), 9),
     "c2h": ("C2 geometry with half-pixel refinement on the dense grid (origin 5, 4582 blocks/pair)",
             640, 480, dict(subpixel=1), 4),
     "c1b": ("C1 geometry in batch: 64x64, published sparse 5x5 grid, half-pixel refinement",
