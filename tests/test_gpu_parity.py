@@ -657,7 +657,7 @@ def test_batch_path_is_graph_capturable(aof, orc, synth, gpu_device, kw):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
-    for rep in range(2):
+    for rep in range(8):  # (the per-pair predictor and sums go through the scalar cache: stale lines would show here)
         hp, hc, _ = synth.make_batch(128, 96, n, 9 if kw else 4, 3000 + 10 * rep, noise=4,
                                      brightness=6 if kw else 0)
         prev.copy_(torch.from_numpy(hp))
