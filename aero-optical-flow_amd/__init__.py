@@ -98,6 +98,7 @@ def _load():
         "aof_search_variant": (C.c_char_p, [VP]),
         "aof_set_force_generic": (C.c_int, [VP, C.c_int]),
         "aof_set_search_mode": (C.c_int, [VP, C.c_int]),
+        "aof_set_pipeline": (C.c_int, [VP, I64]),
         "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
         "aof_flow_pair_host": (C.c_int, [VP, VP, VP, VP, VP, VP]),
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
@@ -251,6 +252,10 @@ class FlowEngine:
         """SEARCH_EXHAUSTIVE (default), SEARCH_PRUNED (exact, data-dependent rate) or
         SEARCH_EXHAUSTIVE_STRIPS (exhaustive search in the LDS-strip kernel)."""
         self._check(lib.aof_set_search_mode(self._ctx, int(mode)))
+
+    def set_pipeline(self, sub_pairs):
+        """Two-level batches: pairs per pipelined sub-batch (0 = off, < 0 = automatic, the default)."""
+        self._check(lib.aof_set_pipeline(self._ctx, int(sub_pairs)))
 
     def set_profiling(self, on=True, kernels=None):
         """Time every kernel (kernels=None) or only the given kernel ids with HIP events."""

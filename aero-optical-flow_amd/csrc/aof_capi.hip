@@ -51,7 +51,15 @@ struct aof_ctx {
     hipGraphExec_t push_graph[2];
     bool graph_disabled;        // capture failed once: stay on the plain path
     bool capturing;
+    // two-level batches: coarse passes (K1, level-1 search and reduce) of sub-batch i+1 run on
+    // `aux` under the level-0 search of sub-batch i (DESIGN.md "C3 pipeline")
+    hipStream_t aux;
+    hipEvent_t *pipe_ev;        // [kPipeEvents]: fork + per-sub-batch coarse-done / fine-done
+    int64_t pipeline_pairs;     // sub-batch size: 0 = off, < 0 = automatic
 };
+
+constexpr int kPipeMaxSub = 64;                  // sub-batches per call at most
+constexpr int kPipeEvents = 1 + 2 * kPipeMaxSub;
 
 namespace {
 
@@ -156,6 +164,94 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, uint32_t *parts
     return 0;
 }
 
+// Device views of one batch: frames, outputs and the workspace regions (all [n_pairs]-major).
+struct BatchView {
+    const uint8_t *prev, *cur;
+    int64_t stride;
+    uint32_t *sums;
+    uint8_t *l1_prev, *l1_cur;
+    aof_block *blocks1; uint8_t *subdirs1; aof_flow *flows1; uint8_t *hist1;
+    aof_block *blocks0; uint8_t *subdirs0; aof_flow *flows; uint8_t *hist0;
+};
+
+FlowTail flow_tail(const aof_ctx *ctx, int level, aof_flow *flows, const aof_flow *pred)
+{
+    const aof_params &p = ctx->params;
+    FlowTail t;
+    t.nblocks = (level ? ctx->g1 : ctx->g0).blocks(); t.range = level_range(p, level);
+    t.hist_filter = p.hist_filter; t.min_valid = p.min_valid;
+    t.flows = flows; t.pred = pred; t.emit_predictor = level ? 1 : 0;
+    return t;
+}
+
+// One level of pairs [first, first+n): search, then K3 unless the search kernel reduced itself.
+int enqueue_level(aof_ctx *ctx, int level, SearchArgs a, const FlowTail &tail, uint8_t *hist, int kid_search,
+                  int kid_reduce, hipStream_t s)
+{
+    const uint32_t *parts = nullptr;
+    int nstrips = 0, rc;
+    bool reduced = false;
+    {
+        Timed t(ctx, kid_search, s);
+        rc = run_search(ctx, a, tail, reinterpret_cast<uint32_t *>(hist), &parts, &nstrips, &reduced, s);
+        if (rc) return rc;
+    }
+    if (reduced) return 0;
+    ReduceArgs r;
+    r.parts = parts; r.nstrips = nstrips;
+    r.blocks = a.blocks; r.subdirs = a.subdirs;
+    r.value_threshold = value_threshold_u16(ctx->params);
+    r.tail = tail; r.n_pairs = a.n_pairs;
+    r.chunk_parts = reinterpret_cast<uint32_t *>(hist);
+    Timed t(ctx, kid_reduce, s);
+    rc = launch_reduce(r, s);
+    if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+// Coarse passes of pairs [first, first+n): pixel sums, level-1 frames, level-1 search and its
+// reduction (the predictor).  Nothing to do for one level without equalisation.
+int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, hipStream_t s)
+{
+    const aof_params &p = ctx->params;
+    const bool two = p.pyramid_levels == 2, eq = p.mean_subtract != 0;
+    if (!two && !eq) return 0;
+    const int64_t l1_frame = (int64_t)(p.width / 2) * (p.height / 2);
+    uint32_t *sums = v.sums ? v.sums + first * 4 : nullptr;
+    if (eq) HIP_TRY(ctx, hipMemsetAsync(sums, 0, (size_t)n * 4 * sizeof(uint32_t), s));
+    PyramidArgs a;
+    a.prev = v.prev + first * v.stride; a.cur = v.cur + first * v.stride; a.pair_stride = v.stride;
+    a.w = p.width; a.h = p.height;
+    a.l1_prev = two ? v.l1_prev + first * l1_frame : nullptr;
+    a.l1_cur = two ? v.l1_cur + first * l1_frame : nullptr;
+    a.sums = sums; a.n_pairs = n;
+    {
+        Timed t(ctx, AOF_K_PYRAMID, s);
+        const int rc = launch_pyramid(a, s);
+        if (rc) return fail(ctx, -EIO, "pyramid launch: %s", hipGetErrorString((hipError_t)rc));
+    }
+    if (!two) return 0;
+    const int64_t nb1 = ctx->g1.blocks();
+    SearchArgs sa = search_args(ctx, 1, a.l1_prev, a.l1_cur, l1_frame, v.blocks1 + first * nb1,
+                                v.subdirs1 ? v.subdirs1 + first * nb1 : nullptr, nullptr, sums, n);
+    return enqueue_level(ctx, 1, sa, flow_tail(ctx, 1, v.flows1 + first, nullptr),
+                         v.hist1 + (size_t)first * hist_bytes_per_pair(p, 1), AOF_K_SEARCH_L1, AOF_K_REDUCE_L1, s);
+}
+
+// Level-0 search (under the level-1 predictor when there is one) and the final reduction.
+int enqueue_fine(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, hipStream_t s)
+{
+    const aof_params &p = ctx->params;
+    const bool two = p.pyramid_levels == 2;
+    const int64_t nb0 = ctx->g0.blocks();
+    const aof_flow *pred = two ? v.flows1 + first : nullptr;
+    SearchArgs sa = search_args(ctx, 0, v.prev + first * v.stride, v.cur + first * v.stride, v.stride,
+                                v.blocks0 + first * nb0, v.subdirs0 ? v.subdirs0 + first * nb0 : nullptr, pred,
+                                v.sums ? v.sums + first * 4 : nullptr, n);
+    return enqueue_level(ctx, 0, sa, flow_tail(ctx, 0, v.flows + first, pred),
+                         v.hist0 + (size_t)first * hist_bytes_per_pair(p, 0), AOF_K_SEARCH, AOF_K_REDUCE, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -180,6 +276,16 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
     grid_for_level(*p, 0, &ctx->g0);
     if (p->pyramid_levels == 2) grid_for_level(*p, 1, &ctx->g1);
     std::snprintf(ctx->err, sizeof(ctx->err), "ok");
+    ctx->pipeline_pairs = 0;   // opt-in: measured slower than one pass on this stack
+    if (p->pyramid_levels == 2) {
+        // made here, not on first use: the batch path must stay capturable into a hipGraph
+        DeviceGuard guard(device);
+        ctx->pipe_ev = new (std::nothrow) hipEvent_t[kPipeEvents]();
+        bool ok = ctx->pipe_ev && hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < kPipeEvents; i++)
+            ok = hipEventCreateWithFlags(&ctx->pipe_ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { aof_destroy(ctx); return -EIO; }
+    }
 
     *out = ctx;
     return 0;
@@ -195,6 +301,11 @@ void aof_destroy(aof_ctx *ctx)
                 for (int e = 0; e < 2; e++)
                     if (ctx->ev[k][r][e]) (void)hipEventDestroy(ctx->ev[k][r][e]);
         delete[] ctx->ev;
+    }
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->pipe_ev) {
+        for (int i = 0; i < kPipeEvents; i++) if (ctx->pipe_ev[i]) (void)hipEventDestroy(ctx->pipe_ev[i]);
+        delete[] ctx->pipe_ev;
     }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 2; i++) if (ctx->push_graph[i]) (void)hipGraphExecDestroy(ctx->push_graph[i]);
@@ -332,82 +443,67 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
                                   "device is %d", ctx->device, cur_dev);
 
     hipStream_t s = static_cast<hipStream_t>(stream);
+    BatchView v;
     uint8_t *ws = static_cast<uint8_t *>(d_workspace);
     const bool two = p.pyramid_levels == 2, eq = p.mean_subtract != 0;
-    uint32_t *sums = eq ? reinterpret_cast<uint32_t *>(ws + L.sums) : nullptr;
-    aof_block *blocks0 = d_blocks ? d_blocks : reinterpret_cast<aof_block *>(ws + L.l0_blocks);
-    uint8_t *subdirs0 = nullptr;
-    if (p.subpixel) subdirs0 = d_subdirs ? d_subdirs : ws + L.l0_subdirs;
+    v.prev = d_prev; v.cur = d_cur; v.stride = pair_stride;
+    v.sums = eq ? reinterpret_cast<uint32_t *>(ws + L.sums) : nullptr;
+    v.l1_prev = two ? ws + L.l1_prev : nullptr;
+    v.l1_cur = two ? ws + L.l1_cur : nullptr;
+    v.blocks1 = reinterpret_cast<aof_block *>(ws + L.l1_blocks);
+    v.subdirs1 = p.subpixel ? ws + L.l1_subdirs : nullptr;
+    v.flows1 = reinterpret_cast<aof_flow *>(ws + L.l1_flows);
+    v.hist1 = ws + L.l1_hist;
+    v.blocks0 = d_blocks ? d_blocks : reinterpret_cast<aof_block *>(ws + L.l0_blocks);
+    v.subdirs0 = nullptr;
+    if (p.subpixel) v.subdirs0 = d_subdirs ? d_subdirs : ws + L.l0_subdirs;
+    v.flows = d_flows;
+    v.hist0 = ws + L.l0_hist;
 
-    if (eq) HIP_TRY(ctx, hipMemsetAsync(sums, 0, (size_t)n_pairs * 4 * sizeof(uint32_t), s));
-    if (two || eq) {
-        PyramidArgs a;
-        a.prev = d_prev; a.cur = d_cur; a.pair_stride = pair_stride;
-        a.w = p.width; a.h = p.height;
-        a.l1_prev = two ? ws + L.l1_prev : nullptr;
-        a.l1_cur = two ? ws + L.l1_cur : nullptr;
-        a.sums = sums; a.n_pairs = n_pairs;
-        Timed t(ctx, AOF_K_PYRAMID, s);
-        rc = launch_pyramid(a, s);
-        if (rc) return fail(ctx, -EIO, "pyramid launch: %s", hipGetErrorString((hipError_t)rc));
-    }
-    const aof_flow *pred = nullptr;
-    const uint32_t *parts = nullptr;
-    int nstrips = 0;
-    bool reduced = false;
-    if (two) {
-        aof_block *blocks1 = reinterpret_cast<aof_block *>(ws + L.l1_blocks);
-        uint8_t *subdirs1 = p.subpixel ? ws + L.l1_subdirs : nullptr;
-        aof_flow *flows1 = reinterpret_cast<aof_flow *>(ws + L.l1_flows);
-        const int64_t l1_stride = (int64_t)(p.width / 2) * (p.height / 2);
-        FlowTail tail1;
-        tail1.nblocks = ctx->g1.blocks(); tail1.range = level_range(p, 1);
-        tail1.hist_filter = p.hist_filter; tail1.min_valid = p.min_valid;
-        tail1.flows = flows1; tail1.pred = nullptr; tail1.emit_predictor = 1;
-        {
-            SearchArgs a = search_args(ctx, 1, ws + L.l1_prev, ws + L.l1_cur, l1_stride, blocks1,
-                                       subdirs1, nullptr, sums, n_pairs);
-            Timed t(ctx, AOF_K_SEARCH_L1, s);
-            rc = run_search(ctx, a, tail1, reinterpret_cast<uint32_t *>(ws + L.l1_hist), &parts, &nstrips,
-                            &reduced, s);
-            if (rc) return rc;
+    // Two levels: the coarse passes are HBM-bound (K1 streams both frames) and the level-0
+    // search is VALU-bound, so a large batch is cut into sub-batches and the coarse passes of
+    // sub-batch i+1 run on a second stream under the level-0 search of sub-batch i.  Sub-batches
+    // are sized so that the frames K1 has just streamed are still in the 256 MiB memory-side
+    // cache when the level-0 search reads them again; the coarse stream is held two sub-batches
+    // ahead at most for the same reason.
+    int64_t sub = 0;
+    if (two && ctx->aux && ctx->pipeline_pairs != 0) {
+        sub = ctx->pipeline_pairs;
+        if (sub < 0) {
+            const int64_t pair_bytes = 2 * (int64_t)p.width * p.height;
+            sub = (64ll << 20) / pair_bytes;
+            if (sub < 16) sub = 16;
         }
-        if (!reduced) {
-            ReduceArgs r;
-            r.parts = parts; r.nstrips = nstrips;
-            r.blocks = blocks1; r.subdirs = subdirs1;
-            r.value_threshold = value_threshold_u16(p);
-            r.tail = tail1; r.n_pairs = n_pairs;
-            r.chunk_parts = reinterpret_cast<uint32_t *>(ws + L.l1_hist);
-            Timed t(ctx, AOF_K_REDUCE_L1, s);
-            rc = launch_reduce(r, s);
-            if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));
-        }
-        pred = flows1;
+        if ((n_pairs + sub - 1) / sub > kPipeMaxSub) sub = (n_pairs + kPipeMaxSub - 1) / kPipeMaxSub;
+        if (n_pairs < 2 * sub) sub = 0;   // nothing to overlap
     }
-    FlowTail tail0;
-    tail0.nblocks = ctx->g0.blocks(); tail0.range = level_range(p, 0);
-    tail0.hist_filter = p.hist_filter; tail0.min_valid = p.min_valid;
-    tail0.flows = d_flows; tail0.pred = pred; tail0.emit_predictor = 0;
-    {
-        SearchArgs a = search_args(ctx, 0, d_prev, d_cur, pair_stride, blocks0, subdirs0, pred, sums,
-                                   n_pairs);
-        Timed t(ctx, AOF_K_SEARCH, s);
-        rc = run_search(ctx, a, tail0, reinterpret_cast<uint32_t *>(ws + L.l0_hist), &parts, &nstrips,
-                        &reduced, s);
+    if (sub == 0) {
+        rc = enqueue_coarse(ctx, v, 0, n_pairs, s);
+        if (!rc) rc = enqueue_fine(ctx, v, 0, n_pairs, s);
+        return rc;
+    }
+    hipEvent_t *ev = ctx->pipe_ev;
+    const int nsub = (int)((n_pairs + sub - 1) / sub);
+    HIP_TRY(ctx, hipEventRecord(ev[0], s));             // fork: aux starts behind the caller's stream
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ev[0], 0));
+    for (int i = 0; i < nsub; i++) {
+        const int64_t first = (int64_t)i * sub, count = n_pairs - first < sub ? n_pairs - first : sub;
+        if (i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ev[2 + 2 * (i - 2)], 0));  // fine(i-2) done
+        rc = enqueue_coarse(ctx, v, first, count, ctx->aux);
         if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(ev[1 + 2 * i], ctx->aux));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ev[1 + 2 * i], 0));   // join (the last one joins aux for good)
+        rc = enqueue_fine(ctx, v, first, count, s);
+        if (rc) return rc;
+        if (i + 2 < nsub) HIP_TRY(ctx, hipEventRecord(ev[2 + 2 * i], s));
     }
-    if (!reduced) {
-        ReduceArgs r;
-        r.parts = parts; r.nstrips = nstrips;
-        r.blocks = blocks0; r.subdirs = subdirs0;
-        r.value_threshold = value_threshold_u16(p);
-        r.tail = tail0; r.n_pairs = n_pairs;
-        r.chunk_parts = reinterpret_cast<uint32_t *>(ws + L.l0_hist);
-        Timed t(ctx, AOF_K_REDUCE, s);
-        rc = launch_reduce(r, s);
-        if (rc) return fail(ctx, -EIO, "reduce launch: %s", hipGetErrorString((hipError_t)rc));
-    }
+    return 0;
+}
+
+int aof_set_pipeline(aof_ctx *ctx, int64_t sub_pairs)
+{
+    if (!ctx) return -EINVAL;
+    ctx->pipeline_pairs = sub_pairs;
     return 0;
 }
 

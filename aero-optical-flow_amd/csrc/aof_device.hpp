@@ -5,9 +5,19 @@
 
 #include <cstdint>
 
+#include "aof_internal.hpp"
+
 namespace aof {
 
 typedef unsigned long long u64;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Fourth dword of a raw (untyped, stride 0) buffer resource on gfx950: DATA_FORMAT = 32.
+constexpr int kRawBuffer = 0x00020000;
+
+// n / d for n < 2^31 with the host-made magic number of aof_internal.hpp.
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shift; }
 
 // Spec "Mean": round-half-up integer mean; delta = mean(prev) - mean(cur).
 // sums layout: [pair][frame: 0 prev, 1 cur][level].

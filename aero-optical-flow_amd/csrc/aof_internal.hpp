@@ -15,6 +15,23 @@
 
 namespace aof {
 
+// n / d for n < 2^31 as (umulhi(n, mul) + n) >> shift (round-up method of Granlund & Montgomery;
+// with n < 2^31 the sum cannot overflow 32 bits).  Filled on the host, used by the lane-per-block
+// kernels, where a run-time integer division costs ~20 VALU instructions per lane.
+struct FastDiv {
+    uint32_t mul, shift;
+};
+inline FastDiv fastdiv_make(uint32_t d)
+{
+    FastDiv f = {0u, 0u};
+    if (d == 0) return f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    f.mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.shift = l;
+    return f;
+}
+
 struct Grid {
     int32_t x0, y0, step_x, step_y, nx, ny;
     AOF_HD int32_t blocks() const { return nx * ny; }
@@ -32,7 +49,8 @@ bool tile8_geometry(const aof_params &p, int level);  // level can run the tile8
 int grid_for_level(const aof_params &p, int level, Grid *g);
 int level_range(const aof_params &p, int level);  // histogram half-range R
 int value_threshold_u16(const aof_params &p);     // SAD gate clamped to the u16 record
-int reduce_chunks(int nblocks);                   // 0: one reduction workgroup per pair reads all records
+int reduce_chunks(int nblocks);
+size_t hist_bytes_per_pair(const aof_params &p, int level);  // vote-histogram scratch of one pair                   // 0: one reduction workgroup per pair reads all records
 
 // What turns a pair's vote histograms into its aof_flow (K3).
 struct FlowTail {
@@ -64,7 +82,8 @@ struct SearchArgs {
     int64_t n_pairs;
     uint32_t *hist_parts;      // tile8 only: [n_pairs][nstrips][2][2*(2R+1)+1] per-strip vote histograms
     int32_t hist_range;        // R
-    int32_t prune;             // tile8 only: exact partial-distortion elimination
+    int32_t prune;             // exact partial-distortion elimination (lane8, tile8, tile16)
+    FastDiv div_nb, div_nx;    // lane8: filled by its launchers (item -> pair, block -> row)
 };
 
 struct ReduceArgs {

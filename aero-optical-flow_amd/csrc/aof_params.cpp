@@ -112,6 +112,24 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 using namespace aof;
 
+namespace aof {
+
+// Bytes of per-pair vote-histogram scratch of a level: per-strip histograms of the tile8 search
+// or per-chunk histograms of the two-step reduction of large grids, whichever is larger.
+size_t hist_bytes_per_pair(const aof_params &p, int level)
+{
+    Grid g;
+    if (grid_for_level(p, level, &g)) return 0;
+    const size_t bins = 2 * (2 * (size_t)level_range(p, level) + 1) + 1;
+    size_t bytes = 0;
+    if (tile8_geometry(p, level))
+        bytes = (size_t)plan_tile8(p.width >> level, g.nx, g.ny).nstrips * 2 * bins * sizeof(uint32_t);
+    const size_t need = (size_t)reduce_chunks(g.blocks()) * 2 * bins * sizeof(uint32_t);
+    return need > bytes ? need : bytes;
+}
+
+}  // namespace aof
+
 extern "C" {
 
 int aof_version(void) { return AOF_VERSION; }
@@ -236,22 +254,8 @@ int aof_workspace_layout(const aof_params *p, int64_t n_pairs, aof_ws_layout *ou
     out->l0_blocks = off;   off = align_up(off + n * (size_t)g0.blocks() * sizeof(aof_block), 256);
     out->l0_subdirs = off;  off = align_up(off + n * (size_t)g0.blocks(), 256);
     for (int level = 0; level < p->pyramid_levels; level++) {
-        size_t bytes = 0;
-        if (tile8_geometry(*p, level)) {
-            const Grid &g = level ? g1 : g0;
-            const Tile8Plan pl = plan_tile8(p->width >> level, g.nx, g.ny);
-            const size_t bins = 2 * (2 * (size_t)level_range(*p, level) + 1) + 1;
-            bytes = n * (size_t)pl.nstrips * 2 * bins * sizeof(uint32_t);
-        }
-        {   // grids too large for one reduction workgroup per pair: per-chunk vote histograms
-            const Grid &g = level ? g1 : g0;
-            const size_t chunks = (size_t)reduce_chunks(g.blocks());
-            const size_t bins = 2 * (2 * (size_t)level_range(*p, level) + 1) + 1;
-            const size_t need = n * chunks * 2 * bins * sizeof(uint32_t);
-            if (need > bytes) bytes = need;
-        }
         (level ? out->l1_hist : out->l0_hist) = off;
-        off = align_up(off + bytes, 256);
+        off = align_up(off + n * hist_bytes_per_pair(*p, level), 256);
     }
     out->total_bytes = off ? off : 256;
     return 0;

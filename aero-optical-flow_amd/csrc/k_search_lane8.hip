@@ -199,21 +199,21 @@ __device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint3
 // start_row / prune_pays are the wave's hints carried from its previous chunk of blocks (every
 // lane of the wave stays in the control flow until the search is over, so ballots see them all).
 template <bool SUBPIXEL, bool PRUNE>
-__device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, int blk, int64_t item, bool live,
+__device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, uint32_t blk, uint32_t item, bool live,
                                             aof_block &rec, int &start_row, int &prune_pays)
 {
-    const int bx = blk % a.grid.nx, by = blk / a.grid.nx;
-    const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y;
+    const uint32_t by = fast_div(blk, a.div_nx), bx = blk - by * (uint32_t)a.grid.nx;
+    const int i = a.grid.x0 + (int)bx * a.grid.step_x, j = a.grid.y0 + (int)by * a.grid.step_y;
     const int W = a.w;
     constexpr int m = SUBPIXEL ? 1 : 0;
     int px = 0, py = 0, delta = 0;
+    // Almost every wave lies inside one pair.  Everything that depends on the pair alone is
+    // computed for the wave's FIRST pair in scalar registers -- frame base addresses, predictor,
+    // equalisation delta (scalar loads, served by the constant cache) -- and only the lanes of a
+    // following pair correct it: a per-lane load here would be a whole memory round trip in front
+    // of the 24 row loads, and a per-lane 64-bit base address costs two VALU per row.
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair);
     if (live) {
-        // Per-pair inputs (predictor, pixel sums).  Almost every wave lies inside one pair: fetch
-        // them for the wave's first pair through a wave-uniform address (scalar loads, served by
-        // the constant cache) and only the lanes of a following pair through their own -- a
-        // per-lane load here is a full memory round trip in front of the 24 row loads.
-        const int64_t first = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pair >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pair);
         typedef const __attribute__((address_space(4))) uint32_t *const_u32;  // read-only during the kernel
         if (a.pred) {
             const uint32_t w3 = ((const_u32)(a.pred + first))[3];  // quality, flags, pred_x, pred_y
@@ -222,7 +222,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
         }
         if (a.sums) {
             const uint32_t npix = (uint32_t)(a.w * a.h);
-            const const_u32 sm = (const_u32)(a.sums + first * 4);
+            const const_u32 sm = (const_u32)(a.sums + (size_t)first * 4);
             delta = (int)((sm[a.level] + npix / 2) / npix) - (int)((sm[2 + a.level] + npix / 2) / npix);
             if (pair != first) delta = equalise_delta(a.sums, pair, a.level, npix);
         }
@@ -239,16 +239,32 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
         }
         return 8;
     }
-    const uint8_t *pr = a.prev + pair * a.pair_stride + (int64_t)j * W + i;
-    const uint8_t *pc = a.cur + pair * a.pair_stride + (int64_t)wy0 * W + wx0;
+    // Row loads through buffer resources: the descriptor (base of the wave's first pair) and the
+    // row offset r*W live in scalar registers, the lane contributes ONE 32-bit byte offset -- no
+    // VALU per row.  Reads past the last pair's frame return zero instead of faulting.
+    const uint64_t span = a.n_pairs > 1 ? (uint64_t)(a.n_pairs - first) * (uint64_t)a.pair_stride
+                                        : (uint64_t)a.w * (uint64_t)a.h;
+    const uint32_t records = span > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)span;
+    const int64_t base = (int64_t)first * a.pair_stride;
+    const __amdgpu_buffer_rsrc_t rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.prev) + base, 0, records, kRawBuffer);
+    const __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.cur) + base, 0, records, kRawBuffer);
+    const uint32_t dp = (pair - first) * (uint32_t)a.pair_stride;   // lane8_supported: fits 32 bits
+    const uint32_t off_prev = dp + (uint32_t)(j * W + i);
+    const uint32_t off_cur = dp + (uint32_t)(wy0 * W + wx0);
 
     uint32_t ref[8][2];
     uint4 win[16];
     if (inside) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) __builtin_memcpy(ref[r], pr + r * W, 8);
+        for (int r = 0; r < 8; r++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_prev, off_prev, r * W, 0);
+            ref[r][0] = v.x; ref[r][1] = v.y;
+        }
 #pragma unroll
-        for (int s = 0; s < 16; s++) __builtin_memcpy(&win[s], pc + s * W, 16);
+        for (int s = 0; s < 16; s++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off_cur, s * W, 0);
+            win[s] = make_uint4(v.x, v.y, v.z, v.w);
+        }
     }
     uint32_t gradient = 0;
     if (inside) gradient = gradient_gate(ref);
@@ -300,14 +316,13 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
     int subdir = 8;
     if constexpr (SUBPIXEL) {
         if ((uint32_t)rec.sad < (uint32_t)a.value_threshold) {
-            const uint8_t *ring = pc + (idx / 9 - 1) * W + (idx % 9 - 1);
+            const uint32_t ring = off_cur + (uint32_t)((idx / 9 - 1) * W + (idx % 9 - 1));
             uint32_t rows[10][3];
 #pragma unroll
             for (int y = 0; y < 10; y++) {
-                uint16_t tail;
-                __builtin_memcpy(rows[y], ring + y * W, 8);
-                __builtin_memcpy(&tail, ring + y * W + 8, 2);
-                rows[y][2] = tail;
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_cur, ring, y * W, 0);
+                rows[y][0] = v.x; rows[y][1] = v.y;
+                rows[y][2] = __builtin_amdgcn_raw_buffer_load_b16(rs_cur, ring + 8, y * W, 0);
             }
             RefineState<2> st;
             st.init();
@@ -333,27 +348,28 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, int64_t pair, i
 // PRUNE: a workgroup walks `spw` consecutive 256-item chunks (block rows further down the same
 // frame) and each wave carries the dy row where its previous chunk matched.
 template <bool SUBPIXEL, bool PRUNE>
-__device__ __forceinline__ void search_chunks(const SearchArgs &a, int64_t items, uint32_t total_wgs, int spw)
+__device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t items, uint32_t total_wgs, int spw)
 {
     // consecutive workgroups = consecutive block rows of one pair: keep them on one XCD, whose L2
     // then serves the search rows that vertically adjacent blocks share
-    const int64_t wg = (int64_t)xcd_remap(blockIdx.x, total_wgs);
-    const int nb = a.grid.blocks();
+    const uint32_t wg = xcd_remap(blockIdx.x, total_wgs);
+    const uint32_t nb = (uint32_t)a.grid.blocks();
     int start_row = 4, prune_pays = 1;
     for (int c = 0; c < spw; c++) {
-        const int64_t item = (wg * spw + c) * kThreads + threadIdx.x;
+        const uint32_t item0 = (wg * (uint32_t)spw + (uint32_t)c) * kThreads;   // < 2^31 (launcher)
+        const uint32_t item = item0 + threadIdx.x;
         const bool live = item < items;
         if (!PRUNE && !live) return;
-        if (PRUNE && (item - threadIdx.x) >= items) return;   // whole workgroup past the end (uniform)
-        const int64_t pair = live ? item / nb : 0;
+        if (PRUNE && item0 >= items) return;   // whole workgroup past the end (uniform)
+        const uint32_t pair = live ? fast_div(item, a.div_nb) : 0u;
         aof_block rec;
-        (void)search_block<SUBPIXEL, PRUNE>(a, pair, live ? (int)(item - pair * nb) : 0, item, live, rec, start_row,
+        (void)search_block<SUBPIXEL, PRUNE>(a, pair, live ? item - pair * nb : 0u, item, live, rec, start_row,
                                             prune_pays);
     }
 }
 
 template <bool SUBPIXEL>
-__global__ __launch_bounds__(kThreads, 4) void k_search_lane8(SearchArgs a, int64_t items, uint32_t total_wgs, int spw)
+__global__ __launch_bounds__(kThreads, 4) void k_search_lane8(SearchArgs a, uint32_t items, uint32_t total_wgs, int spw)
 {
     search_chunks<SUBPIXEL, false>(a, items, total_wgs, spw);
 }
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_search_lane8(SearchArgs a, int6
 // The pruned search holds both code paths (pruned rows and the exhaustive fallback) and keeps
 // the whole window live across a data-dependent loop: three waves per SIMD (168 VGPRs).
 template <bool SUBPIXEL>
-__global__ __launch_bounds__(kThreads, 3) void k_search_lane8_pruned(SearchArgs a, int64_t items, uint32_t total_wgs,
+__global__ __launch_bounds__(kThreads, 3) void k_search_lane8_pruned(SearchArgs a, uint32_t items, uint32_t total_wgs,
                                                                       int spw)
 {
     search_chunks<SUBPIXEL, true>(a, items, total_wgs, spw);
@@ -376,18 +392,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_flow_lane8(SearchArgs a, FlowTa
     extern __shared__ uint32_t s_votes[];  // [ppw][2][n]
     const int nb = a.grid.blocks(), tid = threadIdx.x;
     const int centre = 2 * a.hist_range + 1, n = 2 * centre + 1;
-    const int64_t pair0 = (int64_t)blockIdx.x * ppw;
-    const int np = (int)min((int64_t)ppw, a.n_pairs - pair0);
+    const uint32_t pair0 = blockIdx.x * (uint32_t)ppw;   // pairs * blocks < 2^31 per launch (launcher)
+    const int np = (int)min((int64_t)ppw, a.n_pairs - (int64_t)pair0);
     for (int k = tid; k < ppw * 2 * n; k += kThreads) s_votes[k] = 0;
     __syncthreads();
     const bool live = tid < np * nb;
-    const int p = live ? tid / nb : 0, blk = live ? tid - p * nb : 0;
+    const int p = live ? (int)fast_div((uint32_t)tid, a.div_nb) : 0, blk = live ? tid - p * nb : 0;
     aof_block rec;
     rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
     int subdir = 8;
     int start_row = 4, prune_pays = 1;  // (unused: the grouped kernel always searches exhaustively)
-    if (live) subdir = search_block<SUBPIXEL, false>(a, pair0 + p, blk, (pair0 + p) * nb + blk, true, rec, start_row,
-                                                     prune_pays);
+    if (live) subdir = search_block<SUBPIXEL, false>(a, pair0 + (uint32_t)p, (uint32_t)blk,
+                                                     (pair0 + (uint32_t)p) * (uint32_t)nb + (uint32_t)blk, true, rec,
+                                                     start_row, prune_pays);
     const bool ok = live && (uint32_t)rec.sad < (uint32_t)a.value_threshold;  // skipped = 0xFFFF
     const int hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
     const int hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
@@ -408,31 +425,67 @@ __global__ __launch_bounds__(kThreads, 4) void k_flow_lane8(SearchArgs a, FlowTa
 
 }  // namespace
 
+// One launch indexes its (pair, block) items with 31 bits; larger batches are cut into several.
+constexpr int64_t kMaxItems = 0x7FFF0000ll;
+
 bool lane8_supported(const SearchArgs &a)
 {
     if (a.tile != 8 || a.search != 4) return false;
-    if ((int64_t)a.w * a.h > 0x7FFFFFFF) return false;
-    return a.n_pairs <= 0x7FFFFFFFll * kThreads / (a.grid.blocks() > 0 ? a.grid.blocks() : 1);
+    const int64_t frame = (int64_t)a.w * a.h;
+    const int nb = a.grid.blocks();
+    if (frame > 0x7FFFFFFF || nb < 1 || nb >= (1 << 24)) return false;
+    // a wave's lanes address their frames with 32-bit offsets from the wave's first pair
+    const int64_t span = 64 / nb + 2;
+    if (a.n_pairs > 1 && (a.pair_stride < 0 || span * a.pair_stride + frame > 0xFFFFFFFFll)) return false;
+    return true;
 }
+
+namespace {
+
+// Runs `launch(slice, pairs_done)` over slices of at most kMaxItems (pair, block) items.
+template <typename F>
+int for_slices(const SearchArgs &a, F &&launch)
+{
+    const int nb = a.grid.blocks();
+    const int64_t per = kMaxItems / nb;
+    for (int64_t done = 0; done < a.n_pairs; done += per) {
+        SearchArgs s = a;
+        s.n_pairs = a.n_pairs - done < per ? a.n_pairs - done : per;
+        s.prev += done * a.pair_stride;
+        s.cur += done * a.pair_stride;
+        s.blocks += done * nb;
+        if (s.subdirs) s.subdirs += done * nb;
+        if (s.pred) s.pred += done;
+        if (s.sums) s.sums += done * 4;
+        s.div_nb = fastdiv_make((uint32_t)nb);
+        s.div_nx = fastdiv_make((uint32_t)a.grid.nx);
+        const int rc = launch(s, done);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
 
 int launch_search_lane8(const SearchArgs &a, void *stream)
 {
     if (a.n_pairs == 0) return 0;
     if (a.subpixel && !a.subdirs) return (int)hipErrorInvalidValue;
-    const int64_t items = a.n_pairs * a.grid.blocks();
-    const int64_t chunks = (items + kThreads - 1) / kThreads;
-    // pruned search: consecutive chunks per workgroup so that all but the first inherit a start
-    // row; fewer when the launch is small and needs the workgroups for parallelism
-    int spw = 1;
-    if (a.prune) spw = chunks >= 4 * 4096 ? 4 : (chunks >= 2 * 4096 ? 2 : 1);
-    const int64_t wgs = (chunks + spw - 1) / spw;
-    if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
-    void (*fn)(SearchArgs, int64_t, uint32_t, int);
-    if (a.prune) fn = a.subpixel ? k_search_lane8_pruned<true> : k_search_lane8_pruned<false>;
-    else fn = a.subpixel ? k_search_lane8<true> : k_search_lane8<false>;
-    hipLaunchKernelGGL(fn, dim3((uint32_t)wgs), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a, items,
-                       (uint32_t)wgs, spw);
-    return (int)hipGetLastError();
+    return for_slices(a, [&](const SearchArgs &s, int64_t) {
+        const int64_t items = s.n_pairs * s.grid.blocks();
+        const int64_t chunks = (items + kThreads - 1) / kThreads;
+        // pruned search: consecutive chunks per workgroup so that all but the first inherit a start
+        // row; fewer when the launch is small and needs the workgroups for parallelism
+        int spw = 1;
+        if (s.prune) spw = chunks >= 4 * 4096 ? 4 : (chunks >= 2 * 4096 ? 2 : 1);
+        const int64_t wgs = (chunks + spw - 1) / spw;
+        void (*fn)(SearchArgs, uint32_t, uint32_t, int);
+        if (s.prune) fn = s.subpixel ? k_search_lane8_pruned<true> : k_search_lane8_pruned<false>;
+        else fn = s.subpixel ? k_search_lane8<true> : k_search_lane8<false>;
+        hipLaunchKernelGGL(fn, dim3((uint32_t)wgs), dim3(kThreads), 0, static_cast<hipStream_t>(stream), s,
+                           (uint32_t)items, (uint32_t)wgs, spw);
+        return (int)hipGetLastError();
+    });
 }
 
 // Pairs per workgroup of the grouped kernel; 0 = the grid does not qualify.
@@ -448,14 +501,17 @@ int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream)
     if (a.n_pairs == 0) return 0;
     const int ppw = lane8_group(a);
     if (ppw == 0) return (int)hipErrorInvalidValue;
-    const int64_t wgs = (a.n_pairs + ppw - 1) / ppw;
-    if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     const int n = 2 * (2 * a.hist_range + 1) + 1;
     if (a.subpixel && !a.subdirs) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(a.subpixel ? k_flow_lane8<true> : k_flow_lane8<false>, dim3((uint32_t)wgs), dim3(kThreads),
-                       (size_t)ppw * 2 * n * sizeof(uint32_t),
-                       static_cast<hipStream_t>(stream), a, tail, ppw);
-    return (int)hipGetLastError();
+    return for_slices(a, [&](const SearchArgs &s, int64_t done) {
+        FlowTail t = tail;
+        t.flows += done;
+        if (t.pred) t.pred += done;
+        const int64_t wgs = (s.n_pairs + ppw - 1) / ppw;
+        hipLaunchKernelGGL(s.subpixel ? k_flow_lane8<true> : k_flow_lane8<false>, dim3((uint32_t)wgs), dim3(kThreads),
+                           (size_t)ppw * 2 * n * sizeof(uint32_t), static_cast<hipStream_t>(stream), s, t, ppw);
+        return (int)hipGetLastError();
+    });
 }
 
 }  // namespace aof

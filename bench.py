@@ -95,6 +95,47 @@ def host_cores():
     return n
 
 
+def spawn_ranks(n):
+    """Re-launch this command line under torch.distributed.run with n ranks on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(args, rank, world):
+    """The N>1 control flow of the batched mode with placeholder records and no GPU: every rank
+    fills its shard's 16-byte records with the GLOBAL pair index, the ranks gather them, and
+    every rank checks that it sees all pairs in order."""
+    import importlib
+    import torch.distributed as dist
+    ge.load_package()
+    batch = importlib.import_module(ge.PKG_NAME + ".batch")
+    if world > 1:
+        dist.init_process_group("gloo")
+    total = args.pairs if args.scaling == "strong" else args.pairs * world
+    b, e = batch.shard_range(total, rank, world)
+    local = torch.arange(b, e, dtype=torch.int32).view(-1, 1).repeat(1, 4).contiguous().view(torch.uint8).view(-1, 16)
+    full = batch.gather_flows(local, total)
+    ok = bool(torch.equal(full.view(torch.int32).view(-1, 4)[:, 0], torch.arange(total, dtype=torch.int32)))
+    if world > 1:
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_ranks": world, "global_pairs": total, "scaling": args.scaling,
+                          "gathered_in_pair_order_on_every_rank": ok}), flush=True)
+    return 0 if ok else 1
+
+
 def bench_c1(args, aof, rank, world, dist):
     """configs[0]: the reference's own call shape -- ONE 64x64 frame per calcFlow() call from
     a host buffer through the C++ facade (PX4Flow sparse grid, half-pixel refinement).
@@ -239,15 +280,28 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = rehearsal of the N>1 "
                          "control flow with several ranks sharing the GPUs that exist")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="two-level workloads: pairs per pipelined sub-batch (coarse passes of sub-batch i+1 on a "
+                         "second stream under the level-0 search of sub-batch i); 0 = off (default), -1 = automatic")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step's launch sequence into a hipGraph and replay it per step")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="rehearse the N>1 control flow without a GPU: rendezvous, shard, gather a batch of "
+                         "placeholder flow records over gloo, print one line and leave (CPU test of the launch path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU,
+        # torch.distributed.run on the loopback address) BEFORE anything here touches the GPU,
+        # and leave with the launcher's exit code.
+        return spawn_ranks(args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+    if args.rendezvous_only:
+        return rendezvous_only(args, rank, world)
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -281,6 +335,7 @@ def main():
         eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
     if args.force_generic:
         eng.force_generic(True)
+    eng.set_pipeline(args.pipeline)
     if args.scaling == "strong":
         sb, se = batch.shard_range(args.pairs, rank, world)
         n = se - sb
@@ -304,20 +359,41 @@ def main():
     ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=device)
 
     state = {"i": 0, "pending": None, "gathered": None}
+    graphs = None
+    if args.graph:
+        graphs = []
+        for f in flows2:   # one graph per flow buffer (the gather of step i overlaps step i+1)
+            eng.flow_batch(prev, cur, blocks=blocks, flows=f, workspace=ws)
+            torch.cuda.synchronize(device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.flow_batch(prev, cur, blocks=blocks, flows=f, workspace=ws)
+            graphs.append(g)
 
     def step():
         # Two flow buffers alternate so that the gather of step i (the only exchange of the
         # batched mode: 16 B per pair, every rank gets all flows) crosses xGMI on RCCL's
         # stream while step i+1's search is already enqueued.
         f = flows2[state["i"] & 1]
+        if graphs is not None and not eng_profiling["on"]:
+            graphs[state["i"] & 1].replay()
+        else:
+            eng.flow_batch(prev, cur, blocks=blocks, flows=f, workspace=ws)
         state["i"] += 1
-        eng.flow_batch(prev, cur, blocks=blocks, flows=f, workspace=ws)
         if world == 1:
             return
         if state["pending"] is not None:
             state["gathered"] = state["pending"].wait()
         src = f.cpu() if args.backend == "gloo" else f  # gloo (rehearsal) gathers host copies
         state["pending"] = batch.gather_flows_async(src, world * n)
+
+    eng_profiling = {"on": False}
+    _set_prof = eng.set_profiling
+
+    def set_profiling(on, kernels=None):
+        eng_profiling["on"] = bool(on)
+        _set_prof(on, kernels=kernels) if kernels is not None else _set_prof(on)
+    eng.set_profiling = set_profiling
 
     def drain():
         if state["pending"] is not None:
@@ -345,6 +421,15 @@ def main():
             torch.cuda.synchronize(device)
     fence()
     eng.set_profiling(True, kernels=[aof.K_SEARCH])
+    step()
+    fence()
+    lps = max(1, len(eng.profile_ms(aof.K_SEARCH)))   # K2 launches per step (pipelined sub-batches)
+    # One K2 launch per step: its events are recorded inside the timed region.  A pipelined step
+    # has one K2 launch per sub-batch on a stream that other kernels overlap; bracketing each
+    # with events would serialise what the pipeline overlaps, so the timed region then runs
+    # without events and K2 is timed in a second pass of the same K steps right after it.
+    events_in_timed_region = lps == 1 and not args.graph
+    eng.set_profiling(events_in_timed_region, kernels=[aof.K_SEARCH])
     for _ in range(args.warmup):
         step()
     fence()
@@ -353,6 +438,11 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if not events_in_timed_region:
+        eng.set_profiling(True, kernels=[aof.K_SEARCH])
+        for _ in range(args.steps):
+            step()
+        fence()
     eng.set_profiling(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
@@ -360,8 +450,10 @@ def main():
         elapsed = float(t.item())
 
     # ---- dominant kernel against its roofline (rank 0's launches) ----
-    k2 = eng.profile_ms(aof.K_SEARCH)[-args.steps:]
-    k2_ms = float(np.mean(k2)) if k2 else float("nan")
+    # (the event ring keeps the last 256 launches: whole steps only)
+    k2 = eng.profile_ms(aof.K_SEARCH)
+    k2 = k2[len(k2) - min(args.steps, len(k2) // lps) * lps:]
+    k2_ms = float(np.sum(k2)) / (len(k2) // lps) if k2 else float("nan")
     eng.set_profiling(True)          # all kernels, outside the timed region
     for _ in range(5):
         step()
@@ -370,37 +462,49 @@ def main():
     per_kernel = {}
     for name, kid in (("pyramid", aof.K_PYRAMID), ("search_l1", aof.K_SEARCH_L1),
                       ("reduce_l1", aof.K_REDUCE_L1), ("search", aof.K_SEARCH), ("reduce", aof.K_REDUCE)):
-        v = eng.profile_ms(kid)[-5:]
-        if v:
-            per_kernel[name] = round(float(np.mean(v)), 5)
+        v = eng.profile_ms(kid)
+        if v:   # per step: the sum over the step's sub-batch launches
+            per_kernel[name] = round(float(np.sum(v)) / 5, 5)
     per_kernel["search"] = round(k2_ms, 5)  # the timed region's own measurement
     alg_bytes = aof.algorithmic_bytes(p)
     achieved = alg_bytes * n / (k2_ms * 1e-3) / 1e9
-    traffic = None
+    # `traffic` is NOT measured in this run: PMC counters need rocprofv3 around the process.  It is
+    # read from the committed summary of the same command under profiles/ (tools/collect_evidence.sh);
+    # `traffic_source` names the file, or says that no summary exists for this workload and size.
+    traffic, traffic_source = None, f"none: profiles/pmc_traffic.json has no entry {args.workload}:{n}"
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
         try:
-            tj = json.load(open(tfile))
-            ent = tj.get(f"{args.workload}:{n}")
+            ent = json.load(open(tfile)).get(f"{args.workload}:{n}")
             if ent:
                 traffic = ent["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+                traffic_source = ent.get("source", "profiles/pmc_traffic.json")
+        except Exception as e:
+            traffic_source = f"none: profiles/pmc_traffic.json unreadable ({e})"
+    step_ms = elapsed / args.steps * 1e3
+    achieved_step = alg_bytes * n / (step_ms * 1e-3) / 1e9   # the whole step (every kernel + gaps), per GPU
 
     out = {
         "metric": f"frame-pairs/s ({W}x{H}, {p.tile}x{p.tile} SAD, +-{p.search} search)",
         "value": round(world * n * args.steps / elapsed, 1),
         "unit": "frame-pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle_steps,
+        "ms_per_step": round(step_ms, 4),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_gpu": n, "global_pairs": world * n,
-                   "search_kernel": eng.variant, "search": args.search, "noise_lsb": args.noise, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
+                   "search_kernel": eng.variant, "search": args.search, "k2_launches_per_step": lps, "noise_lsb": args.noise, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": traffic_source,
+                     # the same algorithmic bytes over the WHOLE step (all kernels of the workload and
+                     # the gaps between them): the figure to quote for multi-kernel workloads (c3, c5p)
+                     "achieved_step": round(achieved_step, 1), "frac_step": round(achieved_step / HBM_PEAK_GBS, 4),
                      "kernel": "k_search (K2)", "kernel_ms": round(k2_ms, 5),
+                     "kernel_ms_from": "HIP events on the launch stream inside the timed region" if events_in_timed_region
+                     else f"HIP events in a second pass of the same {args.steps} steps (sum of the {lps} sub-batch "
+                          "launches of a step, which other kernels overlap): quote frac_step for this workload",
                      "algorithmic_bytes_per_pair": alg_bytes, "pairs_per_launch": n,
                      # nominal abs-diffs of the exhaustive scan; meaningless when candidates are pruned
                      "abs_diff_per_s": round(aof.abs_diffs(p) * n / (k2_ms * 1e-3), 1)
@@ -423,7 +527,9 @@ def main():
             eng.flow_batch(prev, cur, blocks=blocks, flows=flows2[0], workspace=ws)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t1
-        pk2 = float(np.mean(eng.profile_ms(aof.K_SEARCH)[-args.steps:]))
+        pk2 = eng.profile_ms(aof.K_SEARCH)
+        pk2 = pk2[len(pk2) - min(args.steps, len(pk2) // lps) * lps:]
+        pk2 = float(np.sum(pk2)) / (len(pk2) // lps)
         eng.set_profiling(False)
         eng.set_search_mode(aof.SEARCH_EXHAUSTIVE)
         out["exact_pruned_search"] = {
@@ -481,4 +587,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

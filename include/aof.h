@@ -154,6 +154,17 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
                           uint8_t *d_subdirs, aof_flow *d_flows, void *d_workspace,
                           size_t workspace_bytes, void *stream);
 
+/* Two-level configurations cut a large batch into sub-batches and run the HBM-bound coarse
+ * passes (pixel sums + 2x2 pyramid, level-1 search and reduce) of sub-batch i+1 on an internal
+ * second stream under the VALU-bound level-0 search of sub-batch i; everything still joins the
+ * caller's stream before aof_flow_batch_device's work ends, and the call stays capturable.
+ * sub_pairs: pairs per sub-batch; 0 = off (one pass over the whole batch: the default, because
+ * on ROCm 7.2 the cross-stream dependencies cost more than the overlap gains -- DESIGN.md
+ * section 8), < 0 = automatic (about 64 MiB of frames per sub-batch, so that the level-0
+ * search finds the frames K1 streamed a moment ago in the memory-side cache).  Results do
+ * not depend on it. */
+int aof_set_pipeline(aof_ctx *ctx, int64_t sub_pairs);
+
 /* ---- host-buffer conveniences (what the C++ facade calls) ----
  * Synchronous: copy in, run the kernels above, copy out.  blocks/subdirs may be NULL. */
 int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, aof_block *blocks,

@@ -171,6 +171,90 @@ def test_c4_batch_properties_at_full_size(aof, orc, synth, gpu_device):
     assert again["blocks"].tobytes() == b.tobytes() and again["flows"].tobytes() == f.tobytes()
 
 
+def test_c4_full_batch_of_1024_pairs_through_the_shard_and_gather_path(aof, orc, synth, gpu_device):
+    """configs[3] at its stated size: 1 024 independent VGA pairs, sharded eight ways exactly as
+    the ranks of an 8-GPU node would (batch.shard_range), every shard through the HIP path, the
+    16-byte flow records joined in pair order by batch.gather_flows (one process here, so the
+    gather is the identity; the world-size-2 gloo test covers the collective itself).  Every
+    pair is checked through the analytic property of a pure translation, a sample against
+    the oracle."""
+    import importlib
+    import torch
+    batch = importlib.import_module("aero_optical_flow_amd.batch")
+    p = aof.default_params(640, 480)
+    n_total, world = 1024, 8
+    canvas_prev, canvas_cur, shifts = synth.make_batch(640, 480, 64, 4, 7000)   # 64 distinct pairs, tiled
+    eng = aof.FlowEngine(p, 0)
+    gathered = []
+    for rank in range(world):
+        b, e = batch.shard_range(n_total, rank, world)
+        idx = np.arange(b, e) % 64
+        tp = torch.from_numpy(canvas_prev[idx]).to(gpu_device)
+        tc = torch.from_numpy(canvas_cur[idx]).to(gpu_device)
+        blocks, flows, _ = eng.flow_batch(tp, tc)
+        full = batch.gather_flows(flows, e - b)          # world of one: the local records
+        torch.cuda.synchronize()
+        gathered.append(full.cpu())
+        bv = aof.blocks_view(blocks)
+        assert (bv["sad"] == 0).all()
+        assert (bv["dx"] == shifts[idx, 0:1]).all() and (bv["dy"] == shifts[idx, 1:2]).all()
+        if rank in (0, 7):
+            sample = [0, 77, 127]
+            check_against_oracle(aof, orc, p, canvas_prev[idx[sample]], canvas_cur[idx[sample]],
+                                 dict(blocks=bv[sample], flows=aof.flows_view(flows)[sample]))
+    f = aof.flows_view(torch.cat(gathered, dim=0))
+    want = shifts[np.arange(n_total) % 64]
+    assert f.shape[0] == n_total
+    assert np.array_equal(f["flow_x"], want[:, 0].astype(np.float32))
+    assert np.array_equal(f["flow_y"], want[:, 1].astype(np.float32))
+    assert (f["quality"] == 255).all() and (f["count"] == 4661).all()
+    # and the whole batch in ONE launch gives the same 16 KB of records
+    idx = np.arange(n_total) % 64
+    tp = torch.from_numpy(canvas_prev[idx]).to(gpu_device)
+    tc = torch.from_numpy(canvas_cur[idx]).to(gpu_device)
+    _, flows, _ = eng.flow_batch(tp, tc)
+    torch.cuda.synchronize()
+    assert aof.flows_view(flows).tobytes() == f.tobytes()
+
+
+@pytest.mark.parametrize("sub", [1, 3, 4])
+@pytest.mark.parametrize("kw", [dict(pyramid_levels=2, mean_subtract=1), dict(pyramid_levels=2, subpixel=1),
+                                dict(pyramid_levels=2, mean_subtract=1, tile=16, search=8, value_threshold=12000)])
+def test_pipelined_sub_batches_give_the_same_records(aof, orc, synth, gpu_device, sub, kw):
+    """Two-level batches run as pipelined sub-batches on two streams (aof_set_pipeline): the
+    records must not depend on the sub-batch size (ragged last sub-batch included), eagerly
+    and when the whole call is captured into a hipGraph and replayed."""
+    import torch
+    W, H = (192, 160) if kw.get("tile") == 16 else (128, 96)
+    p = aof.default_params(W, H, **kw)
+    n = 10
+    hp, hc, _ = synth.make_batch(W, H, n, 9, 5200, noise=3, brightness=5 if kw.get("mean_subtract") else 0)
+    prev = torch.from_numpy(hp).to(gpu_device)
+    cur = torch.from_numpy(hc).to(gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    eng.set_pipeline(0)
+    b0, f0, _ = eng.flow_batch(prev, cur)
+    torch.cuda.synchronize()
+    check_against_oracle(aof, orc, p, hp, hc, dict(blocks=aof.blocks_view(b0), flows=aof.flows_view(f0)))
+    eng.set_pipeline(sub)
+    blocks = torch.zeros_like(b0)
+    flows = torch.zeros_like(f0)
+    ws = torch.zeros(aof.workspace_layout(p, n).total_bytes, dtype=torch.uint8, device=gpu_device)
+    eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(blocks, b0) and torch.equal(flows, f0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+    for rep in range(3):
+        hp, hc, _ = synth.make_batch(W, H, n, 9, 5300 + rep, noise=3, brightness=5 if kw.get("mean_subtract") else 0)
+        prev.copy_(torch.from_numpy(hp))
+        cur.copy_(torch.from_numpy(hc))
+        g.replay()
+        torch.cuda.synchronize()
+        check_against_oracle(aof, orc, p, hp, hc, dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows)))
+
+
 # ---- shapes, options and edge cases ---------------------------------------------
 
 SHAPES = [
