@@ -99,6 +99,7 @@ def _load():
         "aof_set_force_generic": (C.c_int, [VP, C.c_int]),
         "aof_set_search_mode": (C.c_int, [VP, C.c_int]),
         "aof_set_pipeline": (C.c_int, [VP, I64]),
+        "aof_set_split_coarse": (C.c_int, [VP, C.c_int]),
         "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
         "aof_flow_pair_host": (C.c_int, [VP, VP, VP, VP, VP, VP]),
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
@@ -115,7 +116,12 @@ def _load():
         "aof_profile_ms": (C.c_int, [VP, C.c_int, C.c_int, P(C.c_float)]),
     }
     for name, (res, args) in sig.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if os.environ.get("AOF_LIB"):   # A/B timing against an older build of the ABI
+                continue
+            raise
         fn.restype, fn.argtypes = res, args
     return lib, tuple(sig)
 
@@ -253,8 +259,15 @@ class FlowEngine:
         SEARCH_EXHAUSTIVE_STRIPS (exhaustive search in the LDS-strip kernel)."""
         self._check(lib.aof_set_search_mode(self._ctx, int(mode)))
 
+    def set_split_coarse(self, on=True):
+        """Two-level batches: run K1 / level-1 search / level-1 reduce as separate kernels (fills the
+        workspace's level-1 frames) instead of the fused coarse kernel."""
+        self._check(lib.aof_set_split_coarse(self._ctx, int(on)))
+
     def set_pipeline(self, sub_pairs):
         """Two-level batches: pairs per pipelined sub-batch (0 = off, < 0 = automatic, the default)."""
+        if int(sub_pairs) == 0 and not hasattr(lib, "aof_set_pipeline"):
+            return   # (AOF_LIB pointing at an older build)
         self._check(lib.aof_set_pipeline(self._ctx, int(sub_pairs)))
 
     def set_profiling(self, on=True, kernels=None):

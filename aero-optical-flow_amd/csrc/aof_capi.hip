@@ -56,6 +56,7 @@ struct aof_ctx {
     hipStream_t aux;
     hipEvent_t *pipe_ev;        // [kPipeEvents]: fork + per-sub-batch coarse-done / fine-done
     int64_t pipeline_pairs;     // sub-batch size: 0 = off, < 0 = automatic
+    bool split_coarse;          // run K1 / level-1 search / level-1 reduce as separate kernels
 };
 
 constexpr int kPipeMaxSub = 64;                  // sub-batches per call at most
@@ -129,6 +130,22 @@ SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const
     return a;
 }
 
+enum SearchKind { SK_TILE8, SK_TILE16, SK_LANE8_GROUP, SK_LANE8, SK_GENERIC };
+
+// Which search kernel serves these arguments (run_search, enqueue_level and aof_search_variant agree).
+SearchKind search_kind(const aof_ctx *ctx, const SearchArgs &a)
+{
+    if (ctx->force_generic) return SK_GENERIC;
+    // The LDS-strip kernel serves the explicit ..._STRIPS modes; the default exhaustive search of
+    // 8x8 tiles runs lane-per-block straight from L2 (measured faster on every dense
+    // configuration: full lane use, no staging phases, no barriers).
+    const bool strips = ctx->search_mode == AOF_SEARCH_EXHAUSTIVE_STRIPS || ctx->search_mode == AOF_SEARCH_PRUNED_STRIPS;
+    if (strips && tile8_supported(a)) return SK_TILE8;
+    if (tile16_supported(a)) return SK_TILE16;
+    if (lane8_supported(a)) return lane8_group(a) > 0 ? SK_LANE8_GROUP : SK_LANE8;
+    return SK_GENERIC;
+}
+
 // Runs the level's search; *parts_used says whether the kernel wrote per-strip histograms
 // into `parts` (only the tile8 kernel does), in which case K3 sums those instead of the records.
 // *reduced: the search kernel also wrote the pairs' flow records (grouped lane8), no K3 follows.
@@ -139,30 +156,34 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, uint32_t *parts
     *parts_used = nullptr;
     *nstrips = 0;
     *reduced = false;
-    // The LDS-strip kernel serves the pruned search and the explicit EXHAUSTIVE_STRIPS mode; the
-    // default exhaustive search of 8x8 tiles runs lane-per-block straight from L2 (measured
-    // faster on every dense configuration: full lane use, no staging phases, no barriers).
-    const bool strips = ctx->search_mode == AOF_SEARCH_EXHAUSTIVE_STRIPS || ctx->search_mode == AOF_SEARCH_PRUNED_STRIPS;
-    if (!ctx->force_generic && strips && tile8_supported(a)) {
+    switch (search_kind(ctx, a)) {
+    case SK_TILE8:
         a.hist_parts = parts;   // the strips vote (half-pixel offsets included): K3 sums them
         *parts_used = parts;
         *nstrips = plan_tile8(a.w, a.grid.nx, a.grid.ny).nstrips;
         rc = launch_search_tile8(a, s);
-    } else if (!ctx->force_generic && tile16_supported(a)) {
+        break;
+    case SK_TILE16:
         rc = launch_search_tile16(a, s);
         if (!rc && a.subpixel) rc = launch_refine(a, s);
-    } else if (!ctx->force_generic && lane8_supported(a)) {  // refines in the same lane
-        if (lane8_group(a) > 0) {
-            rc = launch_flow_lane8(a, tail, s);  // and finalises the flow records
-            *reduced = true;
-        } else {
-            rc = launch_search_lane8(a, s);
-        }
+        break;
+    case SK_LANE8_GROUP:   // refines in the same lane and finalises the flow records
+        rc = launch_flow_lane8(a, tail, s);
+        *reduced = true;
+        break;
+    case SK_LANE8:
+        rc = launch_search_lane8(a, s);
+        break;
+    default:
+        rc = launch_search_generic(a, s);
     }
-    else rc = launch_search_generic(a, s);
     if (rc) return fail(ctx, -EIO, "search launch: %s", hipGetErrorString((hipError_t)rc));
     return 0;
 }
+
+}  // namespace
+
+namespace {
 
 // Device views of one batch: frames, outputs and the workspace regions (all [n_pairs]-major).
 struct BatchView {
@@ -218,7 +239,28 @@ int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, h
     if (!two && !eq) return 0;
     const int64_t l1_frame = (int64_t)(p.width / 2) * (p.height / 2);
     uint32_t *sums = v.sums ? v.sums + first * 4 : nullptr;
-    if (eq) HIP_TRY(ctx, hipMemsetAsync(sums, 0, (size_t)n * 4 * sizeof(uint32_t), s));
+    if (two && !ctx->force_generic && !ctx->split_coarse) {
+        // K1C: sums, pyramid, level-1 search and predictor of a pair in one workgroup, the
+        // level-1 frames never leave LDS (workspace regions l1_prev / l1_cur stay untouched)
+        CoarseArgs c;
+        c.prev = v.prev + first * v.stride; c.cur = v.cur + first * v.stride; c.pair_stride = v.stride;
+        c.w = p.width; c.h = p.height; c.tile = p.tile; c.search = p.search; c.subpixel = p.subpixel;
+        c.grid = ctx->g1;
+        c.feature_threshold = p.feature_threshold;
+        c.value_threshold = value_threshold_u16(p);
+        c.sums = sums;
+        c.blocks = v.blocks1 + first * ctx->g1.blocks();
+        c.tail = flow_tail(ctx, 1, v.flows1 + first, nullptr);
+        c.n_pairs = n;
+        c.first_generation = 0; c.stagger_groups = 0; c.stagger_ticks = 0;   // chosen by the launcher
+        if (coarse_fused_supported(c)) {
+            Timed t(ctx, AOF_K_PYRAMID, s);
+            const int rc = launch_coarse_fused(c, s);
+            if (rc) return fail(ctx, -EIO, "coarse launch: %s", hipGetErrorString((hipError_t)rc));
+            return 0;
+        }
+    }
+    if (eq) HIP_TRY(ctx, hipMemsetAsync(sums, 0, (size_t)n * 4 * sizeof(uint32_t), s));   // K1 adds with integer atomics
     PyramidArgs a;
     a.prev = v.prev + first * v.stride; a.cur = v.cur + first * v.stride; a.pair_stride = v.stride;
     a.w = p.width; a.h = p.height;
@@ -334,20 +376,24 @@ int aof_get_params(const aof_ctx *ctx, aof_params *out)
 const char *aof_search_variant(const aof_ctx *ctx)
 {
     if (!ctx) return "";
-    if (ctx->force_generic) return "generic";
     // which search kernel will level 0 use? (probe with aligned dummy pointers)
     const aof_params &p = ctx->params;
     SearchArgs probe = search_args(ctx, 0, nullptr, nullptr, (int64_t)p.width * p.height, nullptr, nullptr,
                                    nullptr, nullptr, 1);
-    const bool strips = ctx->search_mode == AOF_SEARCH_EXHAUSTIVE_STRIPS || ctx->search_mode == AOF_SEARCH_PRUNED_STRIPS;
-    if (strips && tile8_supported(probe)) return "tile8_lds";
-    if (tile16_supported(probe)) return "tile16_lds";
-    return lane8_supported(probe) ? "lane8" : "generic";
+    switch (search_kind(ctx, probe)) {
+    case SK_TILE8: return "tile8_lds";
+    case SK_TILE16: return "tile16_lds";
+    case SK_GENERIC: return "generic";
+    default: return "lane8";
+    }
 }
 
 int aof_set_force_generic(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
+    if ((on != 0) != ctx->force_generic)   // captured graphs hold the old kernels
+        for (int i = 0; i < 2; i++)
+            if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
     ctx->force_generic = on != 0;
     return 0;
 }
@@ -497,6 +543,16 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         if (rc) return rc;
         if (i + 2 < nsub) HIP_TRY(ctx, hipEventRecord(ev[2 + 2 * i], s));
     }
+    return 0;
+}
+
+int aof_set_split_coarse(aof_ctx *ctx, int on)
+{
+    if (!ctx) return -EINVAL;
+    if ((on != 0) != ctx->split_coarse)   // captured graphs hold the old kernels
+        for (int i = 0; i < 2; i++)
+            if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
+    ctx->split_coarse = on != 0;
     return 0;
 }
 

@@ -97,6 +97,25 @@ struct ReduceArgs {
     uint32_t *chunk_parts;     // large grids: scratch for per-chunk histograms ([n_pairs][chunks][2][bins]), or nullptr
 };
 
+// The fused coarse kernel (k_coarse): K1 + level-1 search + level-1 reduction of one pair per
+// workgroup, level-1 frames in LDS.
+struct CoarseArgs {
+    const uint8_t *prev, *cur; // level-0 frames
+    int64_t pair_stride;
+    int32_t w, h;              // level-0 frame size
+    int32_t tile, search, subpixel;
+    Grid grid;                 // level-1 block grid
+    int32_t feature_threshold;
+    int32_t value_threshold;   // clamped to <= 0xFFFF
+    uint32_t *sums;            // [n_pairs][2][2] written here (no memset, no atomics), or nullptr
+    aof_block *blocks;         // level-1 records [n_pairs][grid.blocks()]
+    FlowTail tail;             // level-1 flows: the predictor
+    int64_t n_pairs;
+    FastDiv div_nb, div_nx, div_chunks;   // filled by the launcher
+    int32_t first_generation, stagger_groups, stagger_ticks;   // launcher: start-up stagger (0 = choose)
+    int32_t rows_per_sweep;    // launcher: level-1 rows one sweep of the workgroup's lanes covers
+};
+
 struct PyramidArgs {
     const uint8_t *prev, *cur;
     int64_t pair_stride;
@@ -109,6 +128,8 @@ struct PyramidArgs {
 // Kernel launchers (one per .hip file).  All enqueue on `stream` and return the
 // hipError_t of the launch as int (0 = ok).
 int launch_pyramid(const PyramidArgs &a, void *stream);
+bool coarse_fused_supported(const CoarseArgs &a);
+int launch_coarse_fused(const CoarseArgs &a, void *stream);
 int launch_search_generic(const SearchArgs &a, void *stream);
 // K2b: half-pixel refinement of records written by an integer search (tile 8 or 16; today only
 // the 16x16 kernel needs it); fills a.subdirs.

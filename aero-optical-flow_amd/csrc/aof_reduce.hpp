@@ -19,9 +19,10 @@ __device__ __forceinline__ void peak_window(int pos, int n, int *lo, int *hi)
     else if (pos == n - 2) { *lo = pos - 2; *hi = pos + 1; }
 }
 
-__device__ __forceinline__ long long floor_div(long long a, long long b)
+template <typename T>
+__device__ __forceinline__ T floor_div(T a, T b)
 {
-    long long q = a / b;
+    T q = a / b;
     if ((a % b) < 0) q--;
     return q;
 }
@@ -40,6 +41,9 @@ __device__ __forceinline__ void finalise_flow(const FlowTail &a, int64_t pair, c
     out.pred_x = out.pred_y = 0;
     int px = 0, py = 0;
     const long long count = sums[2];
+    // count <= nblocks, |sums| <= n * count, vx <= n * count: with n * nblocks < 2^28 nothing below
+    // leaves 30 bits
+    const bool small = (long long)n * a.nblocks < (1ll << 28);
     if (count > (long long)a.min_valid && count > 0) {
         if (a.hist_filter) {
             int posx = 0, posy = 0;
@@ -56,15 +60,26 @@ __device__ __forceinline__ void finalise_flow(const FlowTail &a, int64_t pair, c
             for (int k = lo; k <= hi; k++) { vy += (uint32_t)k * hist_y[k]; wy += hist_y[k]; }
             out.flow_x = (__fdiv_rn((float)vx, (float)wx) - (float)centre) / 2.0f;
             out.flow_y = (__fdiv_rn((float)vy, (float)wy) - (float)centre) / 2.0f;
-            px = (int)(floor_div(2ll * vx + wx, 2ll * wx) - centre);
-            py = (int)(floor_div(2ll * vy + wy, 2ll * wy) - centre);
+            if (small) {   // every operand below 2^30: 32-bit divisions (a 64-bit one is ~150 instructions)
+                px = floor_div<int>((int)(2 * vx + wx), (int)(2 * wx)) - centre;
+                py = floor_div<int>((int)(2 * vy + wy), (int)(2 * wy)) - centre;
+            } else {
+                px = (int)(floor_div<long long>(2ll * vx + wx, 2ll * wx) - centre);
+                py = (int)(floor_div<long long>(2ll * vy + wy, 2ll * wy) - centre);
+            }
         } else {
             out.flow_x = __fdiv_rn((float)sums[0] * 0.5f, (float)count);
             out.flow_y = __fdiv_rn((float)sums[1] * 0.5f, (float)count);
-            px = (int)floor_div(2ll * sums[0] + count, 2ll * count);
-            py = (int)floor_div(2ll * sums[1] + count, 2ll * count);
+            if (small) {
+                px = floor_div<int>(2 * sums[0] + (int)count, 2 * (int)count);
+                py = floor_div<int>(2 * sums[1] + (int)count, 2 * (int)count);
+            } else {
+                px = (int)floor_div<long long>(2ll * sums[0] + count, 2ll * count);
+                py = (int)floor_div<long long>(2ll * sums[1] + count, 2ll * count);
+            }
         }
-        out.quality = (uint8_t)((unsigned long long)count * 255ull / (unsigned long long)a.nblocks);
+        out.quality = small ? (uint8_t)((uint32_t)count * 255u / (uint32_t)a.nblocks)
+                            : (uint8_t)((unsigned long long)count * 255ull / (unsigned long long)a.nblocks);
         out.flags |= AOF_FLAG_FLOW_VALID;
     }
     if (a.emit_predictor) {

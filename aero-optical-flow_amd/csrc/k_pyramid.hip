@@ -129,6 +129,7 @@ int launch_pyramid(const PyramidArgs &a, void *stream)
         if (rows < 1) rows = 1;
         const int nstrips = (h1 + rows - 1) / rows;
         const int64_t total = a.n_pairs * 2 * nstrips;
+        if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(k_pyramid_vec, dim3((uint32_t)total), dim3(kThreads), 0, s, a, rows,
                            nstrips);
     } else {
@@ -136,6 +137,7 @@ int launch_pyramid(const PyramidArgs &a, void *stream)
         int nstrips = (int)((cells + kItemsPerBlock - 1) / kItemsPerBlock);
         if (nstrips < 1) nstrips = 1;
         const int64_t total = a.n_pairs * 2 * nstrips;
+        if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(k_pyramid_scalar, dim3((uint32_t)total), dim3(kThreads), 0, s, a,
                            nstrips);
     }

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_chunk(ReduceArgs a, int chu
 int launch_reduce(const ReduceArgs &a, void *stream)
 {
     if (a.n_pairs == 0) return 0;
+    if (a.n_pairs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;   // one workgroup (or wave) per pair
     const int chunks = a.parts ? 0 : reduce_chunks(a.tail.nblocks);
     if (chunks > 0 && a.chunk_parts && a.n_pairs * chunks <= 0x7FFFFFFF) {
         hipLaunchKernelGGL(k_reduce_chunk, dim3((uint32_t)(a.n_pairs * chunks)), dim3(kThreads), 0,

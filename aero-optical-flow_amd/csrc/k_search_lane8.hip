@@ -198,7 +198,10 @@ __device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint3
 // Returns the half-pixel direction (8 = none).  PRUNE: the wave-uniform exact pruned search;
 // start_row / prune_pays are the wave's hints carried from its previous chunk of blocks (every
 // lane of the wave stays in the control flow until the search is over, so ballots see them all).
-template <bool SUBPIXEL, bool PRUNE>
+// EQ = false: the launch has no pixel sums (a.sums == nullptr): no equalisation code at all in the
+// kernel (the exhaustive flat kernel is instantiated both ways; its code size and register
+// allocation are what the headline configuration runs on).
+template <bool SUBPIXEL, bool PRUNE, bool EQ = true>
 __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, uint32_t blk, uint32_t item, bool live,
                                             aof_block &rec, int &start_row, int &prune_pays)
 {
@@ -206,24 +209,27 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
     const int i = a.grid.x0 + (int)bx * a.grid.step_x, j = a.grid.y0 + (int)by * a.grid.step_y;
     const int W = a.w;
     constexpr int m = SUBPIXEL ? 1 : 0;
-    int px = 0, py = 0, delta = 0;
+    int px = 0, py = 0, delta = 0, delta_first = 0;
     // Almost every wave lies inside one pair.  Everything that depends on the pair alone is
     // computed for the wave's FIRST pair in scalar registers -- frame base addresses, predictor,
     // equalisation delta (scalar loads, served by the constant cache) -- and only the lanes of a
     // following pair correct it: a per-lane load here would be a whole memory round trip in front
     // of the 24 row loads, and a per-lane 64-bit base address costs two VALU per row.
     const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair);
+    typedef const __attribute__((address_space(4))) uint32_t *const_u32;  // read-only during the kernel
+    const uint32_t npix = (uint32_t)(a.w * a.h);
+    if (EQ && a.sums) {   // (outside the lane-dependent branch: stays in scalar registers)
+        const const_u32 sm = (const_u32)(a.sums + (size_t)first * 4);
+        delta_first = (int)((sm[a.level] + npix / 2) / npix) - (int)((sm[2 + a.level] + npix / 2) / npix);
+    }
     if (live) {
-        typedef const __attribute__((address_space(4))) uint32_t *const_u32;  // read-only during the kernel
         if (a.pred) {
             const uint32_t w3 = ((const_u32)(a.pred + first))[3];  // quality, flags, pred_x, pred_y
             px = (int8_t)(w3 >> 16); py = (int8_t)(w3 >> 24);
             if (pair != first) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
         }
-        if (a.sums) {
-            const uint32_t npix = (uint32_t)(a.w * a.h);
-            const const_u32 sm = (const_u32)(a.sums + (size_t)first * 4);
-            delta = (int)((sm[a.level] + npix / 2) / npix) - (int)((sm[2 + a.level] + npix / 2) / npix);
+        if (EQ && a.sums) {
+            delta = delta_first;
             if (pair != first) delta = equalise_delta(a.sums, pair, a.level, npix);
         }
     }
@@ -303,7 +309,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
             return 8;
         }
     } else {
-        best = exhaustive_search<true>(win, ref, delta);
+        best = exhaustive_search<EQ>(win, ref, delta);
     }
     const int idx = (int)(best & 0xFFFFu);
     rec.dx = (int8_t)(px + idx % 9 - 4);
@@ -347,7 +353,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
 // the other three waves of the SIMD cover that round trip.
 // PRUNE: a workgroup walks `spw` consecutive 256-item chunks (block rows further down the same
 // frame) and each wave carries the dy row where its previous chunk matched.
-template <bool SUBPIXEL, bool PRUNE>
+template <bool SUBPIXEL, bool PRUNE, bool EQ>
 __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t items, uint32_t total_wgs, int spw)
 {
     // consecutive workgroups = consecutive block rows of one pair: keep them on one XCD, whose L2
@@ -363,15 +369,16 @@ __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t item
         if (PRUNE && item0 >= items) return;   // whole workgroup past the end (uniform)
         const uint32_t pair = live ? fast_div(item, a.div_nb) : 0u;
         aof_block rec;
-        (void)search_block<SUBPIXEL, PRUNE>(a, pair, live ? item - pair * nb : 0u, item, live, rec, start_row,
+        rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
+        (void)search_block<SUBPIXEL, PRUNE, EQ>(a, pair, live ? item - pair * nb : 0u, item, live, rec, start_row,
                                             prune_pays);
     }
 }
 
-template <bool SUBPIXEL>
+template <bool SUBPIXEL, bool EQ>
 __global__ __launch_bounds__(kThreads, 4) void k_search_lane8(SearchArgs a, uint32_t items, uint32_t total_wgs, int spw)
 {
-    search_chunks<SUBPIXEL, false>(a, items, total_wgs, spw);
+    search_chunks<SUBPIXEL, false, EQ>(a, items, total_wgs, spw);
 }
 
 // The pruned search holds both code paths (pruned rows and the exhaustive fallback) and keeps
@@ -380,7 +387,7 @@ template <bool SUBPIXEL>
 __global__ __launch_bounds__(kThreads, 3) void k_search_lane8_pruned(SearchArgs a, uint32_t items, uint32_t total_wgs,
                                                                       int spw)
 {
-    search_chunks<SUBPIXEL, true>(a, items, total_wgs, spw);
+    search_chunks<SUBPIXEL, true, true>(a, items, total_wgs, spw);
 }
 
 // Grouped mapping for grids of a few dozen blocks (the published sparse grid): a workgroup owns
@@ -481,7 +488,8 @@ int launch_search_lane8(const SearchArgs &a, void *stream)
         const int64_t wgs = (chunks + spw - 1) / spw;
         void (*fn)(SearchArgs, uint32_t, uint32_t, int);
         if (s.prune) fn = s.subpixel ? k_search_lane8_pruned<true> : k_search_lane8_pruned<false>;
-        else fn = s.subpixel ? k_search_lane8<true> : k_search_lane8<false>;
+        else if (s.sums) fn = s.subpixel ? k_search_lane8<true, true> : k_search_lane8<false, true>;
+        else fn = s.subpixel ? k_search_lane8<true, false> : k_search_lane8<false, false>;
         hipLaunchKernelGGL(fn, dim3((uint32_t)wgs), dim3(kThreads), 0, static_cast<hipStream_t>(stream), s,
                            (uint32_t)items, (uint32_t)wgs, spw);
         return (int)hipGetLastError();

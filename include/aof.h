@@ -154,6 +154,13 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
                           uint8_t *d_subdirs, aof_flow *d_flows, void *d_workspace,
                           size_t workspace_bytes, void *stream);
 
+/* Two-level configurations of 8x8 tiles whose two level-1 frames fit one CU's LDS (VGA: 150 KB)
+ * run their coarse passes -- pixel sums, 2x2 pyramid, level-1 search, level-1 reduction -- as
+ * ONE kernel, a workgroup per pair, and never write the level-1 frames to memory (the
+ * workspace regions l1_prev / l1_cur then stay untouched).  on = 1 runs them as the separate
+ * kernels K1 / K2 / K3 instead, which also fills l1_prev / l1_cur (tests compare the two). */
+int aof_set_split_coarse(aof_ctx *ctx, int on);
+
 /* Two-level configurations cut a large batch into sub-batches and run the HBM-bound coarse
  * passes (pixel sums + 2x2 pyramid, level-1 search and reduce) of sub-batch i+1 on an internal
  * second stream under the VALU-bound level-0 search of sub-batch i; everything still joins the

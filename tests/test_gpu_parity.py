@@ -10,11 +10,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_gpu(aof, p, prevs, curs, device, force_generic=False, want_ws=False, strips=False):
+def run_gpu(aof, p, prevs, curs, device, force_generic=False, want_ws=False, strips=False, split_coarse=False):
     import torch
     eng = aof.FlowEngine(p, 0)
     if force_generic:
         eng.force_generic(True)
+    if split_coarse:
+        eng.set_split_coarse(True)
     if strips:
         eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
     tp = torch.from_numpy(np.ascontiguousarray(prevs)).to(device)
@@ -104,13 +106,16 @@ def test_c2_generic_kernel_agrees(aof, orc, synth, gpu_device):
     check_against_oracle(aof, orc, p, prevs, curs, b)
 
 
-@pytest.mark.parametrize("force_generic", [False, True])
-def test_c3_vga_two_level_mean_subtracted(aof, orc, synth, gpu_device, force_generic):
-    """configs[2]: 640x480, 2-level mean-subtracted pyramid + 4x4 gate / histogram filter."""
+@pytest.mark.parametrize("path", ["fused", "split", "generic"])
+def test_c3_vga_two_level_mean_subtracted(aof, orc, synth, gpu_device, path):
+    """configs[2]: 640x480, 2-level mean-subtracted pyramid + 4x4 gate / histogram filter.
+    fused = the coarse passes in one kernel (k_coarse, level-1 frames in LDS only), split = K1 /
+    level-1 search / level-1 reduce as separate kernels, generic = the wave-per-block kernel."""
     p = aof.default_params(640, 480, pyramid_levels=2, mean_subtract=1)
     # two levels reach 2S at level 1 (+ the level-0 refinement): keep |shift| <= 2S+1 = 9
     prevs, curs, shifts = synth.make_batch(640, 480, 4, 9, 401, noise=3, brightness=13)
-    got = run_gpu(aof, p, prevs, curs, gpu_device, force_generic=force_generic, want_ws=True)
+    got = run_gpu(aof, p, prevs, curs, gpu_device, force_generic=path == "generic", want_ws=True,
+                  split_coarse=path == "split")
     check_against_oracle(aof, orc, p, prevs, curs, got)
     f = got["flows"]
     assert (f["flags"] == 3).all()
@@ -125,10 +130,12 @@ def test_c3_vga_two_level_mean_subtracted(aof, orc, synth, gpu_device, force_gen
     l1p = ws[L.l1_prev:L.l1_prev + 4 * 320 * 240].reshape(4, 240, 320)
     l1c = ws[L.l1_cur:L.l1_cur + 4 * 320 * 240].reshape(4, 240, 320)
     for i in range(4):
-        assert np.array_equal(l1p[i], orc.pyramid_down(prevs[i]))
-        assert np.array_equal(l1c[i], orc.pyramid_down(curs[i]))
+        rp, rc = orc.pyramid_down(prevs[i]), orc.pyramid_down(curs[i])
+        if path != "fused":   # the fused kernel keeps the level-1 frames in LDS
+            assert np.array_equal(l1p[i], rp)
+            assert np.array_equal(l1c[i], rc)
         assert sums[i, 0, 0] == prevs[i].sum(dtype=np.uint64) and sums[i, 1, 0] == curs[i].sum(dtype=np.uint64)
-        assert sums[i, 0, 1] == l1p[i].sum(dtype=np.uint64) and sums[i, 1, 1] == l1c[i].sum(dtype=np.uint64)
+        assert sums[i, 0, 1] == rp.sum(dtype=np.uint64) and sums[i, 1, 1] == rc.sum(dtype=np.uint64)
     # level-1 records against the oracle
     po = orc.params_from(p)
     nb1 = 39 * 29
@@ -253,6 +260,70 @@ def test_pipelined_sub_batches_give_the_same_records(aof, orc, synth, gpu_device
         g.replay()
         torch.cuda.synchronize()
         check_against_oracle(aof, orc, p, hp, hc, dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows)))
+
+
+@pytest.mark.parametrize("shape", [(160, 128), (640, 480), (320, 66), (96, 96), (672, 464), (48, 32)])
+@pytest.mark.parametrize("kw", [dict(), dict(mean_subtract=1), dict(mean_subtract=1, hist_filter=0, min_valid=0)])
+def test_fused_coarse_kernel_equals_the_split_kernels(aof, orc, synth, gpu_device, shape, kw):
+    """k_coarse (sums + pyramid + level-1 search + predictor in one workgroup per pair, level-1
+    frames in LDS) against the separate K1 / K2 / K3 kernels and the oracle: level-1 records,
+    predictors, pixel sums and the final records, on textured, flat, saturated and noisy pairs."""
+    W, H = shape
+    p = aof.default_params(W, H, pyramid_levels=2, **kw)
+    n = 7
+    prevs, curs, _ = synth.make_batch(W, H, n, 9, 8100 + W, noise=4, brightness=11 if kw else 0)
+    prevs[1, : H // 2] = 7                      # flat upper half: gated blocks
+    curs[1, : H // 2] = 7
+    curs[2] = np.minimum(curs[2].astype(np.int32) * 2, 255).astype(np.uint8)   # saturated: the clamp bites
+    prevs[3] = 255 - prevs[3]
+    curs[3] = 255 - curs[3]
+    curs[4] = prevs[4]                          # identical frames
+    prevs[5] = 0                                # black previous frame: everything gated
+    outs = {}
+    for split in (False, True):
+        got = run_gpu(aof, p, prevs, curs, gpu_device, want_ws=True, split_coarse=split)
+        L = aof.workspace_layout(p, n)
+        nb1 = got["eng"].nblocks(1)
+        ws = got["ws"]
+        outs[split] = dict(blocks=got["blocks"].tobytes(), flows=got["flows"].tobytes(),
+                           b1=ws[L.l1_blocks:L.l1_blocks + n * nb1 * 4].tobytes(),
+                           f1=ws[L.l1_flows:L.l1_flows + n * 16].tobytes(),
+                           sums=ws[L.sums:L.sums + n * 16].tobytes() if kw else b"")
+        if not split:
+            check_against_oracle(aof, orc, p, prevs, curs, got)
+    for k in outs[False]:
+        assert outs[False][k] == outs[True][k], f"{k} differs between the fused and the split coarse passes"
+
+
+def test_fused_coarse_kernel_walks_many_pairs_per_workgroup(aof, orc, synth, gpu_device):
+    """k_coarse is persistent (one workgroup per CU walks pairs i, i + CUs, ...) and requests the
+    next pair's first frame rows while it still searches the current one: 1 100 small pairs (four
+    to five per workgroup, ragged tail), every one against the split kernels, a sample against
+    the oracle."""
+    import torch
+    W, H = 96, 64
+    p = aof.default_params(W, H, pyramid_levels=2, mean_subtract=1, min_valid=0)
+    n = 1100
+    hp, hc, _ = synth.make_batch(W, H, 50, 6, 9100, noise=3, brightness=7)
+    idx = (np.arange(n) * 7) % 50
+    prev = torch.from_numpy(hp[idx]).to(gpu_device)
+    cur = torch.from_numpy(hc[(idx + (np.arange(n) // 50)) % 50]).to(gpu_device)   # (also mismatched pairs)
+    outs = []
+    for split in (False, True):
+        eng = aof.FlowEngine(p, 0)
+        eng.set_split_coarse(split)
+        blocks, flows, ws = eng.flow_batch(prev, cur)
+        torch.cuda.synchronize()
+        L = aof.workspace_layout(p, n)
+        w = ws.cpu().numpy()
+        outs.append((blocks.cpu().numpy().tobytes(), flows.cpu().numpy().tobytes(),
+                     w[L.l1_flows:L.l1_flows + 16 * n].tobytes(), w[L.sums:L.sums + 16 * n].tobytes()))
+        if not split:
+            sample = [0, 255, 256, 257, 511, 512, 1023, 1024, 1099]
+            check_against_oracle(aof, orc, p, prev[sample].cpu().numpy(), cur[sample].cpu().numpy(),
+                                 dict(blocks=aof.blocks_view(blocks)[sample], flows=aof.flows_view(flows)[sample]))
+    for k, name in enumerate(("records", "flows", "predictors", "sums")):
+        assert outs[0][k] == outs[1][k], f"{name} differ between the fused and the split coarse passes"
 
 
 # ---- shapes, options and edge cases ---------------------------------------------
