@@ -21,6 +21,10 @@ namespace {
 
 constexpr int kThreads = 512;
 constexpr int kSide = 17;  // 2S+1
+#ifndef AOF_LAB_BOUND_ROWS
+#define AOF_LAB_BOUND_ROWS 2
+#endif
+constexpr int kBoundRows = AOF_LAB_BOUND_ROWS;  // tile rows summed for the lower bound of the pruned search
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 {
@@ -28,6 +32,82 @@ __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 }
 __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | lo; }
 
+// One (dy row, block) item: the SADs of all 17 dx over the NR tile rows first, first + STEP, ...
+// (16, 1 from row 0: the whole tile; 4, 4: a quarter of it -- the lower bound of the pruned search
+// or one lane's share when four lanes split an item).  Leaves the sums in acc (offsets 4g..4g+3,
+// packed u16) and acc16 (offset 16 in the high half, on top of what the caller put there).
+template <int NR, int STEP>
+__device__ __forceinline__ void sum_item(const uint8_t *s_prev, const uint8_t *s_cur, int W, int dyi, int bx, int xs,
+                                         int first, u64 (&acc)[4], uint32_t &acc16)
+{
+    // reference tile rows: 4 dwords at frame column 16*bx + 8
+    uint32_t ref[NR][4];
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const uint2 *p = reinterpret_cast<const uint2 *>(s_prev + (size_t)(first + i * STEP) * W + 16 * bx + 8);
+        const uint2 lo = p[0], hi = p[1];
+        ref[i][0] = lo.x; ref[i][1] = lo.y; ref[i][2] = hi.x; ref[i][3] = hi.y;
+    }
+    const uint8_t *win = s_cur + (size_t)(dyi + first) * W + xs;
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(win + (size_t)(i * STEP) * W);
+        const uint4 q0 = p[0], q1 = p[1];
+        const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        u64 pr[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) pr[j] = pack64(w[j], w[j + 1]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc[g] = qsad(pr[g + k], ref[i][k], acc[g]);
+            acc16 = __builtin_amdgcn_sad_hi_u8(w[4 + k], ref[i][k], acc16);
+        }
+    }
+}
+
+// Smallest packed key (sad << 16 | idx) of a dy row's 17 sums = its first minimum in scan order.
+__device__ __forceinline__ uint32_t row_key(const u64 (&acc)[4], uint32_t acc16, int dyi)
+{
+    uint32_t best = acc16;
+    const uint32_t base = (uint32_t)(dyi * kSide);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t l = (uint32_t)acc[g], h = (uint32_t)(acc[g] >> 32);
+        const uint32_t k0 = (l << 16) | (base + 4 * g + 0), k1 = (l & 0xFFFF0000u) | (base + 4 * g + 1);
+        const uint32_t k2 = (h << 16) | (base + 4 * g + 2), k3 = (h & 0xFFFF0000u) | (base + 4 * g + 3);
+        best = min(best, min(min(k0, k1), min(k2, k3)));
+    }
+    return best;
+}
+
+template <int NR, int STEP>
+__device__ __forceinline__ uint32_t eval_item(const uint8_t *s_prev, const uint8_t *s_cur, int W, int dyi, int bx, int xs,
+                                              int first)
+{
+    u64 acc[4] = {0, 0, 0, 0};
+    uint32_t acc16 = (uint32_t)(dyi * kSide + 16);  // offset 16 as sad<<16 | idx
+    sum_item<NR, STEP>(s_prev, s_cur, W, dyi, bx, xs, first, acc, acc16);
+    return row_key(acc, acc16, dyi);
+}
+
+// Appends the items of the wave's lanes that `keep` to a list in LDS, in lane order, with one
+// atomic per wave: neighbouring list entries stay neighbouring (dy, block) items, so the lanes
+// that later walk the list read neighbouring LDS windows like the exhaustive scan does (a list
+// filled by per-lane atomics comes out shuffled, and its window reads collide in the banks).
+// Must be reached by whole waves.
+__device__ __forceinline__ void wave_append(uint16_t *list, uint32_t *count, bool keep, int item)
+{
+    const unsigned long long m = __ballot(keep);
+    if (m == 0) return;
+    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (keep) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)item;
+}
+
+template <bool PRUNE>
 __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32_t total_wgs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -99,47 +179,118 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     __syncthreads();
 
     const int items = rows_ok ? kSide * nx : 0;
-    for (int item = tid; item < items; item += kThreads) {
-        const int dyi = item / nx, bx = item - dyi * nx;
-        const int xf = 16 * bx + px;                  // moved-frame column of the window start
-        if (xf < 0 || xf + 32 > Wb) continue;         // window leaves the frame: block skipped below
-        const int xs = xf - sh;                       // its 16-aligned LDS column
-        // reference tile: 16 rows x 4 dwords at frame column 16*bx + 8
-        uint32_t ref[16][4];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const uint2 *p = reinterpret_cast<const uint2 *>(s_prev + (size_t)r * W + 16 * bx + 8);
-            const uint2 lo = p[0], hi = p[1];
-            ref[r][0] = lo.x; ref[r][1] = lo.y; ref[r][2] = hi.x; ref[r][3] = hi.y;
+    if constexpr (!PRUNE) {
+        for (int item = tid; item < items; item += kThreads) {
+            const int dyi = item / nx, bx = item - dyi * nx;
+            const int xf = 16 * bx + px;                  // moved-frame column of the window start
+            if (xf < 0 || xf + 32 > Wb) continue;         // window leaves the frame: block skipped below
+            atomicMin(&s_best[bx], eval_item<16, 1>(s_prev, s_cur, W, dyi, bx, xf - sh, 0));
         }
-        u64 acc[4] = {0, 0, 0, 0};                    // offsets 4g .. 4g+3, packed u16
-        uint32_t acc16 = (uint32_t)(dyi * kSide + 16);  // offset 16 as sad<<16 | idx
-        const uint8_t *win = s_cur + (size_t)dyi * W + xs;
+    } else {
+        // Exact pruning (AOF_SEARCH_PRUNED), records bit-identical to the exhaustive scan:
+        //  A  every (dy, block) item sums TWO of its sixteen tile rows for all 17 dx (an eighth of the
+        //     work) and leaves the smallest partial SAD in s_pmin -- a lower bound of every full SAD
+        //     of that dy row;
+        //  B1 four lanes per block evaluate the dy row with the smallest bound completely: under a
+        //     clean match that is the true row, and the block's best key is final;
+        //  B2 every other item whose bound does not exceed the block's best SAD so far may still win
+        //     or TIE (ties go to the earlier scan index): it gets a four-row bound, and if that does
+        //     not exceed the best either it is evaluated completely.  Items with bound > best can
+        //     neither win nor tie (a partial sum only grows) and are dropped.  The items left after
+        //     each step are compacted into a list so that all lanes share them.
+        uint16_t *s_pmin = reinterpret_cast<uint16_t *>(s_best + nx);          // [17][nx]
+        uint16_t *s_list = s_pmin + kSide * nx;                                 // [17 * nx] item ids
+        uint32_t *s_count = reinterpret_cast<uint32_t *>(s_list + kSide * nx);   // (2 * 34 * nx bytes: dword-aligned)
+        if (tid == 0) *s_count = 0;
+        for (int item = tid; item < items; item += kThreads) {
+            const int dyi = item / nx, bx = item - dyi * nx;
+            const int xf = 16 * bx + px;
+            uint32_t bound = 0xFFFFu;
+            if (!(xf < 0 || xf + 32 > Wb)) bound = eval_item<kBoundRows, 16 / kBoundRows>(s_prev, s_cur, W, dyi, bx, xf - sh, 8 / kBoundRows) >> 16;
+            s_pmin[item] = (uint16_t)bound;
+        }
+        __syncthreads();
+        // (four lanes per block, four interleaved tile rows each, sums joined across the quad: the
+        //  step is one item's latency long whatever the lane count, so it is kept a quarter item)
+        for (int q = tid; q < (rows_ok ? 4 * ((nx + 15) / 16 * 16) : 0); q += kThreads) {   // whole waves: shuffles
+            const int bx = q >> 2, part = q & 3;
+            const int xf = 16 * bx + px;
+            const bool in = bx < nx && !(xf < 0 || xf + 32 > Wb);
+            uint32_t m = 0xFFFFFFFFu;                      // (bound << 8 | dy): first smallest bound
+            if (in) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(win + (size_t)r * W);
-            const uint4 q0 = p[0], q1 = p[1];
-            const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            u64 pr[7];
+                for (int d = 0; d < kSide; d++) m = min(m, ((uint32_t)s_pmin[d * nx + bx] << 8) | (uint32_t)d);
+            }
+            const int dyi = (int)(m & 0xFFu);
+            u64 acc[4] = {0, 0, 0, 0};
+            uint32_t acc16 = part == 0 ? (uint32_t)(dyi * kSide + 16) : 0u;   // (the index once per quad)
+            if (in) sum_item<4, 4>(s_prev, s_cur, W, dyi, bx, xf - sh, part, acc, acc16);
+            // u16 lanes cannot carry: a whole tile's SAD is at most 65 280
 #pragma unroll
-            for (int j = 0; j < 7; j++) pr[j] = pack64(w[j], w[j + 1]);
+            for (int o = 1; o <= 2; o <<= 1) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-#pragma unroll
-                for (int g = 0; g < 4; g++) acc[g] = qsad(pr[g + k], ref[r][k], acc[g]);
-                acc16 = __builtin_amdgcn_sad_hi_u8(w[4 + k], ref[r][k], acc16);
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t lo = (uint32_t)acc[g] + (uint32_t)__shfl_xor((int)(uint32_t)acc[g], o, 64);
+                    const uint32_t hi = (uint32_t)(acc[g] >> 32) + (uint32_t)__shfl_xor((int)(uint32_t)(acc[g] >> 32), o, 64);
+                    acc[g] = pack64(lo, hi);
+                }
+                acc16 += (uint32_t)__shfl_xor((int)acc16, o, 64);
+            }
+            if (in && part == 0) {
+                s_pmin[dyi * nx + bx] = 0xFFFFu;           // done: step B2 leaves it alone
+                atomicMin(&s_best[bx], row_key(acc, acc16, dyi));
             }
         }
-        uint32_t best = acc16;
-        const uint32_t base = (uint32_t)(dyi * kSide);
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const uint32_t l = (uint32_t)acc[g], h = (uint32_t)(acc[g] >> 32);
-            const uint32_t k0 = (l << 16) | (base + 4 * g + 0), k1 = (l & 0xFFFF0000u) | (base + 4 * g + 1);
-            const uint32_t k2 = (h << 16) | (base + 4 * g + 2), k3 = (h & 0xFFFF0000u) | (base + 4 * g + 3);
-            best = min(best, min(min(k0, k1), min(k2, k3)));
+        __syncthreads();
+        for (int item0 = tid - (tid & 63); item0 < items; item0 += kThreads) {   // whole waves
+            const int item = item0 + (tid & 63);
+            bool keep = false;
+            if (item < items) {
+                const int dyi = item / nx, bx = item - dyi * nx;
+                const uint32_t bound = s_pmin[item];
+                keep = bound != 0xFFFFu && bound <= (s_best[bx] >> 16);
+            }
+            wave_append(s_list, s_count, keep, item);
         }
-        atomicMin(&s_best[bx], best);
+        __syncthreads();
+        // B2: the survivors of the two-row bound get a four-row bound first (sensor noise lets half
+        // of the two-row bounds through, the four-row bound stops most of those); what survives
+        // that as well is evaluated completely.
+        const int listed = (int)*s_count;
+        __syncthreads();
+        if (tid == 0) *s_count = 0;
+        __syncthreads();
+        uint16_t *s_list2 = s_pmin;   // (the two-row bounds are not read any more: list 2 takes their place)
+        // The second bound is probed on the first round of the list: when it stops less than a
+        // quarter of those items (noise-dominated frames), the rest of the list skips it and is
+        // summed completely at once -- the row then costs the exhaustive scan plus the probes.
+        bool bound_pays = true;
+        for (int k0 = tid - (tid & 63); k0 < listed; k0 += kThreads) {   // whole waves
+            const int k = k0 + (tid & 63);
+            bool keep = false;
+            int item = 0;
+            if (k < listed) {
+                item = s_list[k];
+                keep = true;
+                if (bound_pays) {
+                    const int dyi = item / nx, bx = item - dyi * nx;
+                    const uint32_t bound = eval_item<4, 4>(s_prev, s_cur, W, dyi, bx, 16 * bx + px - sh, 1) >> 16;
+                    keep = bound <= (s_best[bx] >> 16);
+                }
+            }
+            wave_append(s_list2, s_count, keep, item);
+            if (k0 < kThreads && listed > kThreads) {   // after the first round (uniform)
+                __syncthreads();
+                bound_pays = 4 * (int)*s_count <= 3 * kThreads;
+            }
+        }
+        __syncthreads();
+        const int listed2 = (int)*s_count;
+        for (int k = tid; k < listed2; k += kThreads) {
+            const int item = s_list2[k];
+            const int dyi = item / nx, bx = item - dyi * nx;
+            atomicMin(&s_best[bx], eval_item<16, 1>(s_prev, s_cur, W, dyi, bx, 16 * bx + px - sh, 0));
+        }
     }
     __syncthreads();
 
@@ -172,7 +323,12 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     }
 }
 
-size_t tile16_lds(const SearchArgs &a) { return (size_t)48 * a.w + 4 * (size_t)a.grid.nx + 16; }
+size_t tile16_lds(const SearchArgs &a)
+{
+    size_t bytes = (size_t)48 * a.w + 4 * (size_t)a.grid.nx + 16;
+    if (a.prune) bytes += 4 * (size_t)kSide * a.grid.nx + 16;   // lower bounds + item list + counter
+    return bytes;
+}
 
 }  // namespace
 
@@ -193,13 +349,14 @@ int launch_search_tile16(const SearchArgs &a, void *stream)
     const int64_t total = a.n_pairs * a.grid.ny;
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     const size_t lds = tile16_lds(a);
+    void (*fn)(SearchArgs, uint32_t) = a.prune ? k_search_tile16<true> : k_search_tile16<false>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_tile16),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_search_tile16, dim3((uint32_t)total), dim3(kThreads), lds,
-                       static_cast<hipStream_t>(stream), a, (uint32_t)total);
+    hipLaunchKernelGGL(fn, dim3((uint32_t)total), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a,
+                       (uint32_t)total);
     return (int)hipGetLastError();
 }
 

@@ -514,7 +514,8 @@ def main():
 
     # ---- secondary, clearly separate: the opt-in exact-pruning search on the same batch ----
     # (same records bit for bit; data-dependent rate, so never the headline `value`)
-    pruned_available = eng.variant == "lane8" and eng.nblocks(0) > 256  # (the grouped small-grid kernel never prunes)
+    # (the grouped small-grid lane8 kernel never prunes; the 16x16 kernel prunes per (dy row, block) item)
+    pruned_available = (eng.variant == "lane8" and eng.nblocks(0) > 256) or eng.variant == "tile16_lds"
     if args.search == "exhaustive" and pruned_available and not args.force_generic:
         ref_blocks = blocks.clone()
         eng.set_search_mode(aof.SEARCH_PRUNED)

@@ -104,3 +104,74 @@ def test_pruned_fuzz(aof, orc, synth, gpu_device, seed):
     if seed % 3 == 0:
         curs[0] = rng.integers(0, 256, curs[0].shape, dtype=np.uint8)
     both_modes_match_oracle(aof, orc, p, prevs, curs, gpu_device)
+
+
+# ---- 16x16 tiles, +-8 (configs[4] geometry): the same exactness bar for k_search_tile16<PRUNE> ----
+
+def pruned16_matches(aof, orc, p, prevs, curs, device):
+    po = orc.params_from(p)
+    refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(prevs.shape[0])]
+    for mode in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED):
+        b, f = run(aof, p, prevs, curs, device, mode, hint_fill=0x5A, reps=2)
+        for i, r in enumerate(refs):
+            assert b[i].tobytes() == r["blocks"].tobytes(), (mode, i)
+            assert f[i].tobytes() == r["flow"].tobytes(), (mode, i)
+
+
+@pytest.mark.parametrize("noise", [0, 3, 40])
+def test_pruned16_translations_and_noise(aof, orc, synth, gpu_device, noise):
+    p = aof.default_params(320, 256, tile=16, search=8, value_threshold=12000)
+    prevs, curs, _ = synth.make_batch(320, 256, 3, 8, 9400 + noise, noise=noise)
+    pruned16_matches(aof, orc, p, prevs, curs, gpu_device)
+
+
+def test_pruned16_c5_full_size(aof, orc, synth, gpu_device):
+    p = aof.default_params(1280, 960, tile=16, search=8, value_threshold=12000)
+    prevs, curs, shifts = synth.make_batch(1280, 960, 2, 8, 510, noise=2)
+    pruned16_matches(aof, orc, p, prevs, curs, gpu_device)
+
+
+def test_pruned16_ties_flat_and_unrelated_frames(aof, orc, gpu_device):
+    rng = np.random.default_rng(16)
+    H, W = 160, 192
+    img = np.zeros((H, W), np.uint8); img[:, 0::2] = 200          # period 2 in x: ties along dx
+    img2 = np.zeros((H, W), np.uint8); img2[0::2, :] = 150        # period 2 in y: every other dy row ties
+    img3 = np.zeros((H, W), np.uint8); img3[0::4, 0::4] = 255
+    yy, xx = np.mgrid[0:H, 0:W]
+    chk = (((xx // 16 + yy // 16) % 2) * 255).astype(np.uint8)
+    noise_a = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    noise_b = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    half = noise_a.copy(); half[:, : W // 2] = 90                  # half flat: gated blocks
+    prevs = np.stack([img, img2, img3, chk, chk, noise_a, noise_a, half])
+    curs = np.stack([img, img2, img3, chk, 255 - chk, noise_b, noise_a, half])
+    for kw in (dict(), dict(feature_threshold=0, value_threshold=70000), dict(mean_subtract=1)):
+        pruned16_matches(aof, orc, aof.default_params(W, H, tile=16, search=8, **kw), prevs, curs, gpu_device)
+
+
+def test_pruned16_two_level_predictor_and_half_pixel(aof, orc, synth, gpu_device):
+    for kw in (dict(pyramid_levels=2, mean_subtract=1), dict(subpixel=1), dict(pyramid_levels=2, subpixel=1)):
+        p = aof.default_params(320, 256, tile=16, search=8, value_threshold=12000, **kw)
+        reach = 17 if kw.get("pyramid_levels") == 2 else 8
+        prevs, curs, _ = synth.make_batch(320, 256, 3, reach, 9500, noise=3, brightness=9 if kw.get("mean_subtract") else 0)
+        pruned16_matches(aof, orc, p, prevs, curs, gpu_device)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_pruned16_fuzz(aof, orc, synth, gpu_device, seed):
+    rng = np.random.default_rng(1600 + seed)
+    w = int(rng.integers(5, 24)) * 16
+    h = int(rng.integers(40, 130)) * 2
+    kw = dict(width=w, height=h, tile=16, search=8, mean_subtract=int(rng.integers(0, 2)),
+              hist_filter=int(rng.integers(0, 2)), feature_threshold=int(rng.choice([0, 30, 200])),
+              value_threshold=int(rng.choice([0, 2000, 12000, 70000])), min_valid=int(rng.choice([0, 10])))
+    if rng.random() < 0.4:
+        kw["pyramid_levels"] = 2
+    p = aof.default_params(**kw)
+    if aof.check_params(p) != 0:
+        pytest.skip("geometry too small")
+    reach = 17 if p.pyramid_levels == 2 else 8
+    prevs, curs, _ = synth.make_batch(w, h, 3, reach, 9900 + seed, noise=int(rng.integers(0, 30)),
+                                      brightness=int(rng.integers(-25, 26)), contrast=float(rng.choice([1.0, 2.0, 0.2])))
+    if seed % 3 == 0:
+        curs[0] = rng.integers(0, 256, curs[0].shape, dtype=np.uint8)
+    pruned16_matches(aof, orc, p, prevs, curs, gpu_device)
