@@ -408,6 +408,8 @@ def facade_lib():
         f.aof_facade_mavlink_crc.restype = C.c_uint
         f.aof_facade_mavlink_crc.argtypes = [C.c_void_p, C.c_int]
         f.aof_facade_image_width.argtypes = [C.c_void_p]
+        f.aof_facade_set_search_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        f.aof_facade_pyramid_levels.argtypes = [C.c_void_p]
         f.aof_facade_image_height.argtypes = [C.c_void_p]
         f.aof_facade_last_error.restype = C.c_char_p
         f.aof_facade_last_error.argtypes = [C.c_void_p]
@@ -448,6 +450,12 @@ class _FacadeFlow:
 
     def lastError(self):
         return facade_lib().aof_facade_last_error(self._h).decode()
+
+    def setSearchPyramid(self, levels, mean_subtract):
+        return bool(facade_lib().aof_facade_set_search_pyramid(self._h, int(levels), int(bool(mean_subtract))))
+
+    def getPyramidLevels(self):
+        return facade_lib().aof_facade_pyramid_levels(self._h)
 
     def calcFlow(self, img, img_time_us):
         """Returns (quality, dt_us, flow_x_rad, flow_y_rad); the C++ out-parameters keep

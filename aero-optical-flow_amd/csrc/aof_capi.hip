@@ -37,6 +37,7 @@ struct aof_ctx {
     uint8_t *d_pair[2];    // scratch of the stateless two-frame entry point
     int cur_slot;          // slot holding the newest frame
     bool have_prev;
+    bool host_ready;       // everything below exists (ensure_host_state)
     aof_block *d_blocks;
     uint8_t *d_subdirs;
     aof_flow *d_flow;
@@ -591,9 +592,23 @@ int aof_derotate_batch_device(const aof_derotate_params *p, const aof_flow *d_fl
 
 // ---- host-buffer conveniences ------------------------------------------------
 
-static int ensure_host_state(aof_ctx *ctx)
+static void free_host_state(aof_ctx *ctx)
 {
-    if (ctx->d_flow) return 0;
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); ctx->stream = nullptr; }
+    if (ctx->h_frame) { (void)hipHostFree(ctx->h_frame); ctx->h_frame = nullptr; }
+    for (int i = 0; i < 2; i++) if (ctx->h_frames[i]) { (void)hipHostFree(ctx->h_frames[i]); ctx->h_frames[i] = nullptr; }
+    if (ctx->h_flow) { (void)hipHostFree(ctx->h_flow); ctx->h_flow = nullptr; }
+    for (int i = 0; i < 2; i++) if (ctx->d_frames[i]) { (void)hipFree(ctx->d_frames[i]); ctx->d_frames[i] = nullptr; }
+    for (int i = 0; i < 2; i++) if (ctx->d_pair[i]) { (void)hipFree(ctx->d_pair[i]); ctx->d_pair[i] = nullptr; }
+    if (ctx->d_blocks) { (void)hipFree(ctx->d_blocks); ctx->d_blocks = nullptr; }
+    if (ctx->d_subdirs) { (void)hipFree(ctx->d_subdirs); ctx->d_subdirs = nullptr; }
+    if (ctx->d_flow) { (void)hipFree(ctx->d_flow); ctx->d_flow = nullptr; }
+    if (ctx->d_ws) { (void)hipFree(ctx->d_ws); ctx->d_ws = nullptr; }
+    ctx->host_ready = false;
+}
+
+static int alloc_host_state(aof_ctx *ctx)
+{
     const aof_params &p = ctx->params;
     const size_t frame = (size_t)p.width * p.height;
     aof_ws_layout L;
@@ -615,6 +630,21 @@ static int ensure_host_state(aof_ctx *ctx)
         for (int i = 0; i < 2; i++)
             HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_frames[i], frame, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_flow, sizeof(aof_flow), hipHostMallocMapped | hipHostMallocCoherent));
+    return 0;
+}
+
+// Stream, device frames and pinned buffers of the host-buffer entry points, made on first use.
+// A failure half-way frees what was made, so that a later call starts from scratch instead of
+// overwriting (leaking) live handles.
+static int ensure_host_state(aof_ctx *ctx)
+{
+    if (ctx->host_ready) return 0;
+    const int rc = alloc_host_state(ctx);
+    if (rc) {
+        free_host_state(ctx);
+        return rc;
+    }
+    ctx->host_ready = true;
     return 0;
 }
 
@@ -715,8 +745,12 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
         return 1;
     }
     rc = run_one(ctx, frames[ctx->cur_slot], frames[slot], nullptr, nullptr, flow);
+    if (rc) {   // the new frame may be incomplete on the device: do not compare the next one with it
+        ctx->have_prev = false;
+        return rc;
+    }
     ctx->cur_slot = slot;
-    return rc;
+    return 0;
 }
 
 // Same contract as the plain path above, one hipGraphLaunch per frame.
@@ -724,8 +758,12 @@ static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow,
 {
     std::memcpy(ctx->zero_copy ? ctx->h_frames[slot] : ctx->h_frame, frame,
                 (size_t)ctx->params.width * ctx->params.height);
-    HIP_TRY(ctx, hipGraphLaunch(ctx->push_graph[slot], ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipGraphLaunch(ctx->push_graph[slot], ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->have_prev = false;
+        return fail(ctx, -EIO, "graph replay: %s", hipGetErrorString(e));
+    }
     *flow = *ctx->h_flow;
     ctx->cur_slot = slot;
     return 0;

@@ -7,6 +7,17 @@
 // MI355X (num_feat picks the sparse grid: ceil(sqrt(num_feat)) tiles per axis;
 // conf_multi is accepted for source compatibility and unused).  No OpenCV
 // headers or libraries are needed to compile against or link this class.
+//
+// What ships: 8x8 tiles, +-4 px search with half-pixel refinement on TWO levels
+// (half resolution first, its match predicts the full-resolution search) with the
+// frame means equalised per level: per-frame flow up to +-9.5 px (the half-resolution
+// match must lie within its own +-4 px), beyond which the result is not meaningful.  Frames whose size cannot carry two levels
+// (odd width or height, or too small for the half-resolution grid) run one level:
+// +-4.5 px.  getPyramidLevels() / setSearchPyramid() report and change it.
+// Quality is NOT a feature count: it is accepted_tiles * 255 / tiles of the grid
+// (a tile is accepted when it passes the 4x4 gradient gate and its best SAD is below
+// the SAD gate), 0 when ten tiles or fewer were accepted; while integrating towards
+// the output rate, the mean quality of the frames whose quality was > 0.
 #pragma once
 
 #include "optical_flow.hpp"

@@ -38,6 +38,18 @@ public:
 	inline float getFocalLengthY() { return focal_length_y; }
 	inline int getOutputRate() { return output_rate; }
 
+	// Search reach of the engine.  One level: +-(search + 0.5) px per frame (4.5 px with the
+	// defaults); two levels add a half-resolution pass whose match (itself within +-search
+	// half-resolution pixels) predicts the full-resolution search: +-(2 * search + 1.5) px
+	// (9.5 px); mean_subtract equalises the frame means per
+	// level first (the exposure steps of the reference's auto-exposure loop,
+	// /root/reference/src/mainloop.cpp:197-275).  Re-creates the engine: the frame kept by
+	// calcFlow() and the running integration are dropped.  False (and the previous engine
+	// stays) when the geometry does not allow it (two levels need even width and height and a
+	// grid that still fits the half-resolution frame).
+	bool setSearchPyramid(int levels, bool mean_subtract);
+	int getPyramidLevels() const;
+
 	// Text of the last engine error ("ok" when healthy); never throws.
 	const char *lastError() const;
 	// False when the GPU engine could not be created (no gfx950 device).  There is no CPU

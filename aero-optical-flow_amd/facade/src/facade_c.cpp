@@ -53,6 +53,12 @@ int aof_facade_pack_optical_flow_rad(uint64_t offset_ts, uint64_t img_time_us, i
 
 unsigned aof_facade_mavlink_crc(const uint8_t *data, int len) { return mavlinkCrcAccumulate(data, (size_t)len, 0xFFFF); }
 
+int aof_facade_set_search_pyramid(void *flow, int levels, int mean_subtract)
+{
+	return static_cast<OpticalFlow *>(flow)->setSearchPyramid(levels, mean_subtract != 0) ? 1 : 0;
+}
+int aof_facade_pyramid_levels(void *flow) { return static_cast<OpticalFlow *>(flow)->getPyramidLevels(); }
+
 int aof_facade_image_width(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageWidth(); }
 int aof_facade_image_height(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageHeight(); }
 const char *aof_facade_last_error(void *flow) { return static_cast<OpticalFlow *>(flow)->lastError(); }

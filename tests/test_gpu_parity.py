@@ -702,30 +702,127 @@ def test_host_pair_and_streaming_entry_points(aof, orc, synth, gpu_device):
     assert eng.stream_push(frames[3]) is None
 
 
+def facade_oracle_params(aof, orc, cls, w, h):
+    """Oracle parameters of what the facade class ships: OpticalFlowPX4 = the published
+    single-level PX4Flow configuration; OpticalFlowOpenCV = the same grid on two levels with
+    mean equalisation wherever the geometry carries a half-resolution grid."""
+    if cls == "OpticalFlowOpenCV":
+        two = aof.px4flow_params(w, h, pyramid_levels=2, mean_subtract=1)
+        if aof.check_params(two) == 0:
+            return orc.px4flow_params(w, h, pyramid_levels=2, mean_subtract=1), 2
+    return orc.px4flow_params(w, h), 1
+
+
+def same_outputs(got, exp, k):
+    assert got[0] == exp[0], (k, got, exp)
+    if exp[0] >= 0:
+        assert got[1] == exp[1], (k, got, exp)
+        assert np.float32(got[2]).tobytes() == np.float32(exp[2]).tobytes(), (k, got, exp)
+        assert np.float32(got[3]).tobytes() == np.float32(exp[3]).tobytes(), (k, got, exp)
+
+
 @pytest.mark.parametrize("cls", ["OpticalFlowPX4", "OpticalFlowOpenCV"])
 def test_facade_calcflow_matches_oracle(aof, orc, synth, gpu_device, cls):
     """The C++ facade classes (calcFlow contract of mainloop.cpp:322-331) through
     the HIP engine, against the oracle of the same semantics -- bit-exact floats."""
     fx, fy = 216.6677, 216.2457  # /root/reference/src/main.cpp:60-61
-    for rate, size in ((15, (64, 64)), (0, (64, 64)), (40, (128, 128)), (15, (128, 96))):
+    for rate, size in ((15, (64, 64)), (0, (64, 64)), (40, (128, 128)), (15, (128, 96)), (15, (75, 64))):
         flow = getattr(aof, cls)(fx, fy, rate, size[0], size[1])
         assert flow.lastError() == "ok"
         assert (flow.getImageWidth(), flow.getImageHeight()) == size
-        o = orc.Px4(orc.px4flow_params(*size), fx, fy, rate)
+        po, levels = facade_oracle_params(aof, orc, cls, *size)
+        assert flow.getPyramidLevels() == levels
+        if cls == "OpticalFlowOpenCV":
+            assert levels == (1 if size[0] % 2 else 2)
+        o = orc.Px4(po, fx, fy, rate)
         frames, _ = synth.make_sequence(size[0], size[1], 30, 4, seed=rate, max_step=2)
         t, published = 0, 0
         for k in range(30):
             got = flow.calcFlow(frames[k], t)
             exp = o.calc_flow(frames[k], t)
-            assert got[0] == exp[0], (rate, k, got, exp)
+            same_outputs(got, exp, (rate, k))
             if exp[0] >= 0 and k > 0:
                 published += 1
-                assert got[1] == exp[1]
-                assert np.float32(got[2]).tobytes() == np.float32(exp[2]).tobytes()
-                assert np.float32(got[3]).tobytes() == np.float32(exp[3]).tobytes()
             t += 13333
         assert published >= {15: 4, 0: 29, 40: 14}[rate]
         flow.close()
+
+
+@pytest.mark.parametrize("cls", ["OpticalFlowPX4", "OpticalFlowOpenCV"])
+def test_facade_timestamp_wrap_and_frames_without_quality(aof, orc, synth, gpu_device, cls):
+    """Edge paths of the calcFlow contract through the real classes: timestamps that cross
+    2^32 us inside an integration window (mainloop.cpp:305-315 hands over a u32 that wraps),
+    and frames of quality 0 inside a window (flat images: nothing passes the gradient gate),
+    which must neither add flow nor count towards the mean quality."""
+    fx, fy = 216.6677, 216.2457
+    W = H = 128
+    frames, _ = synth.make_sequence(W, H, 40, 4, seed=77, max_step=2)
+    frames = frames.copy()
+    for k in (7, 8, 19, 31):
+        frames[k] = 97                       # flat: quality 0 for the pairs whose PREVIOUS frame it is
+    for rate in (15, 0):
+        flow = getattr(aof, cls)(fx, fy, rate, W, H)
+        po, _ = facade_oracle_params(aof, orc, cls, W, H)
+        o = orc.Px4(po, fx, fy, rate)
+        # time starts at 0 with the first frame (mainloop.cpp:305-315) and wraps after 71 minutes:
+        # three 20-minute gaps, a last one that ends 30 ms short of 2^32 us, then 75 Hz frames, so
+        # that the wrap falls between two frames of one integration window
+        times = [0, 1200000011, 2400000022, 3600000033, (1 << 32) - 30000]
+        while len(times) < 40:
+            times.append(times[-1] + 13333)
+        saw_wrap, zero_quality_published, published = False, 0, 0
+        for k in range(40):
+            got = flow.calcFlow(frames[k], times[k])
+            exp = o.calc_flow(frames[k], times[k] & 0xFFFFFFFF)
+            same_outputs(got, exp, (rate, k))
+            if got[0] >= 0 and k > 0:
+                published += 1
+                assert 0 < got[1] < (1 << 31), "dt_us stays a positive interval across the wrap"
+                if k > 4:
+                    assert got[1] < 200000
+                zero_quality_published += got[0] == 0
+            saw_wrap |= k > 0 and (times[k] >> 32) != (times[k - 1] >> 32)
+        assert saw_wrap and published >= (6 if rate else 39)
+        if rate == 0:
+            assert zero_quality_published >= 4   # every pair whose PREVIOUS frame is flat: nothing passes the gate
+        flow.close()
+
+
+def test_opencv_facade_reaches_beyond_the_single_level_search(aof, orc, synth, gpu_device):
+    """The class mainloop.cpp:423 creates runs two levels: per-frame shifts of 6..9 px (beyond
+    the +-4.5 px of one level; the half-resolution match must lie within its own +-4 px) come out exactly; OpticalFlowPX4 (one level, the published
+    configuration) cannot follow them, and setSearchPyramid() switches either class over."""
+    fx, fy = 216.6677, 216.2457
+    W = H = 128
+    for shift in ((9, -7), (-8, 6), (6, 9), (-9, -9)):
+        steps = np.tile(np.array(shift), (5, 1))
+        pos = np.vstack([[0, 0], np.cumsum(steps, axis=0)])
+        span = int(np.abs(pos).max()) + 1
+        c = synth.canvas(W, H, span, 991 + shift[0])
+        frames = np.stack([c[span - py:span - py + H, span - px:span - px + W] for px, py in pos])
+        cv = aof.OpticalFlowOpenCV(fx, fy, 0, W, H)        # rate 0: every frame publishes
+        px4 = aof.OpticalFlowPX4(fx, fy, 0, W, H)
+        o = orc.Px4(orc.px4flow_params(W, H, pyramid_levels=2, mean_subtract=1), fx, fy, 0)
+        assert cv.getPyramidLevels() == 2 and px4.getPyramidLevels() == 1
+        for k in range(6):
+            got, exp = cv.calcFlow(frames[k], 13333 * k), o.calc_flow(frames[k], 13333 * k)
+            same_outputs(got, exp, (shift, k))
+            one = px4.calcFlow(frames[k], 13333 * k)
+            if k > 0:
+                assert got[0] >= 150      # (tiles whose displaced window leaves the frame drop out)
+                assert np.float32(got[2]) == np.arctan2(np.float32(shift[0]), np.float32(fx)).astype(np.float32)
+                assert np.float32(got[3]) == np.arctan2(np.float32(shift[1]), np.float32(fy)).astype(np.float32)
+                assert abs(np.tan(one[2]) * fx) <= 4.5 + 1e-3, "one level saturates at the search limit"
+        # switching the single-level class to two levels makes it follow as well (fresh state)
+        assert px4.setSearchPyramid(2, True) and px4.getPyramidLevels() == 2
+        o2 = orc.Px4(orc.px4flow_params(W, H, pyramid_levels=2, mean_subtract=1), fx, fy, 0)
+        for k in range(3):   # (time goes on for the live object; the fresh oracle only pins quality and flow)
+            got, exp = px4.calcFlow(frames[k], 13333 * (6 + k)), o2.calc_flow(frames[k], 13333 * k)
+            assert got[0] == exp[0], (shift, "switched", k, got, exp)
+            assert np.float32(got[2]).tobytes() == np.float32(exp[2]).tobytes()
+            assert np.float32(got[3]).tobytes() == np.float32(exp[3]).tobytes()
+        assert not aof.OpticalFlowPX4(fx, fy, 0, 75, 64).setSearchPyramid(2, True)   # odd width: refused, engine kept
+        cv.close(); px4.close()
 
 
 def test_replay_harness_links_and_matches_oracle(aof, orc, synth, gpu_device, tmp_path):
@@ -744,7 +841,7 @@ def test_replay_harness_links_and_matches_oracle(aof, orc, synth, gpu_device, tm
     assert out.returncode == 0, out.stderr
     lines = [l for l in out.stdout.splitlines() if not l.startswith("#")]
     assert "engine: ok" in out.stdout and "DEFAULT_OUTPUT_RATE=15" in out.stdout
-    o = orc.Px4(orc.px4flow_params(crop, crop), 216.6677, 216.2457, 15)
+    o = orc.Px4(facade_oracle_params(aof, orc, "OpticalFlowOpenCV", crop, crop)[0], 216.6677, 216.2457, 15)
     x0, y0 = cam_w // 2 - crop // 2, cam_h // 2 - crop // 2
     n_pub = 0
     for k in range(24):
