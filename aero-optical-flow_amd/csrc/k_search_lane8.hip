@@ -205,8 +205,10 @@ template <bool SUBPIXEL, bool PRUNE, bool EQ = true>
 __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, uint32_t blk, uint32_t item, bool live,
                                             aof_block &rec, int &start_row, int &prune_pays)
 {
-    const uint32_t by = fast_div(blk, a.div_nx), bx = blk - by * (uint32_t)a.grid.nx;
-    const int i = a.grid.x0 + (int)bx * a.grid.step_x, j = a.grid.y0 + (int)by * a.grid.step_y;
+    // (blocks, grid coordinates and pixel offsets stay below 2^24 -- aof_params_check limits a frame to
+    //  2^24 pixels --, so the products are full-rate 24-bit multiplies, not quarter-rate 32-bit ones)
+    const uint32_t by = fast_div(blk, a.div_nx), bx = blk - __umul24(by, (uint32_t)a.grid.nx);
+    const int i = a.grid.x0 + __mul24((int)bx, a.grid.step_x), j = a.grid.y0 + __mul24((int)by, a.grid.step_y);
     const int W = a.w;
     constexpr int m = SUBPIXEL ? 1 : 0;
     int px = 0, py = 0, delta = 0, delta_first = 0;
@@ -255,8 +257,8 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
     const __amdgpu_buffer_rsrc_t rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.prev) + base, 0, records, kRawBuffer);
     const __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.cur) + base, 0, records, kRawBuffer);
     const uint32_t dp = (pair - first) * (uint32_t)a.pair_stride;   // lane8_supported: fits 32 bits
-    const uint32_t off_prev = dp + (uint32_t)(j * W + i);
-    const uint32_t off_cur = dp + (uint32_t)(wy0 * W + wx0);
+    const uint32_t off_prev = dp + (uint32_t)(__mul24(j, W) + i);
+    const uint32_t off_cur = dp + (uint32_t)(__mul24(wy0, W) + wx0);
 
     uint32_t ref[8][2];
     uint4 win[16];
@@ -370,7 +372,7 @@ __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t item
         const uint32_t pair = live ? fast_div(item, a.div_nb) : 0u;
         aof_block rec;
         rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
-        (void)search_block<SUBPIXEL, PRUNE, EQ>(a, pair, live ? item - pair * nb : 0u, item, live, rec, start_row,
+        (void)search_block<SUBPIXEL, PRUNE, EQ>(a, pair, live ? item - __umul24(pair, nb) : 0u, item, live, rec, start_row,
                                             prune_pays);
     }
 }
@@ -440,7 +442,7 @@ bool lane8_supported(const SearchArgs &a)
     if (a.tile != 8 || a.search != 4) return false;
     const int64_t frame = (int64_t)a.w * a.h;
     const int nb = a.grid.blocks();
-    if (frame > 0x7FFFFFFF || nb < 1 || nb >= (1 << 24)) return false;
+    if (frame > (1 << 24) || nb < 1 || nb >= (1 << 24)) return false;   // 24-bit multiplies in the kernels
     // a wave's lanes address their frames with 32-bit offsets from the wave's first pair
     const int64_t span = 64 / nb + 2;
     if (a.n_pairs > 1 && (a.pair_stride < 0 || span * a.pair_stride + frame > 0xFFFFFFFFll)) return false;
@@ -454,7 +456,8 @@ template <typename F>
 int for_slices(const SearchArgs &a, F &&launch)
 {
     const int nb = a.grid.blocks();
-    const int64_t per = kMaxItems / nb;
+    int64_t per = kMaxItems / nb;
+    if (per >= (1 << 24)) per = (1 << 24) - 1;   // pair indices are multiplied in 24 bits
     for (int64_t done = 0; done < a.n_pairs; done += per) {
         SearchArgs s = a;
         s.n_pairs = a.n_pairs - done < per ? a.n_pairs - done : per;

@@ -226,7 +226,8 @@ def bench_ingest(args, aof, device, rank, world, dist):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
            "config": {"workload": "ingest: 640x480 sensor frames, crop 128x128, mask 128x128", "frames_per_gpu": n},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_ingest (K0)",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"ingest:{n}")[0],
+                        "traffic_source": pmc_traffic(f"ingest:{n}")[1], "kernel": "k_ingest (K0)",
                         "kernel_ms": round(k_ms, 5), "algorithmic_bytes_per_frame": alg, "frames_per_launch": n}}
     if rank == 0:
         from oracle import pyoracle as orc
@@ -256,6 +257,64 @@ def bench_ingest(args, aof, device, rank, world, dist):
         dist.destroy_process_group()
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed PMC summary of the same command (profiles/), and its source."""
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            ent = json.load(open(tfile)).get(key)
+            if ent:
+                return ent["hbm_bytes_per_launch"], ent.get("source", "profiles/pmc_traffic.json")
+        except Exception as e:
+            return None, f"none: profiles/pmc_traffic.json unreadable ({e})"
+    return None, f"none: profiles/pmc_traffic.json has no entry {key}"
+
+
+def bench_derotate(args, aof, device, rank, world, dist):
+    """Output-side row of the scope table: gyro de-rotation of a batch of flow
+    records on the device.  Step = one launch over --pairs * 1024 records (default 1 Mi)."""
+    n = args.pairs * 1024
+    g = torch.Generator(device=device)
+    g.manual_seed(5 + rank)
+    flows = torch.zeros((n, 16), dtype=torch.uint8, device=device)
+    flows.view(torch.float32)[:, 0:2] = torch.rand((n, 2), generator=g, device=device) * 8 - 4
+    gyro = torch.rand((n, 4), generator=g, device=device, dtype=torch.float32) * 0.02
+    for _ in range(args.warmup):
+        aof.derotate_batch(flows, gyro, 216.6677, 216.2457, 4.5, 0.01)
+    torch.cuda.synchronize(device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        out = aof.derotate_batch(flows, gyro, 216.6677, 216.2457, 4.5, 0.01)
+        b.record()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    alg = 16 + 16 + 8   # flow record + gyro sample in, two floats out
+    achieved = alg * n / (k_ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic(f"derotate:{n}")
+    line = {"metric": "flow records/s (gyro de-rotation, published PX4Flow compensation)",
+            "value": round(n * args.steps / elapsed, 1), "unit": "records/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "settle_steps": 0, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "derotate: 16-byte flow records + 16-byte gyro samples -> 2 floats", "records_per_launch": n},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+                         "kernel": "k_derotate", "kernel_ms": round(k_ms, 5), "algorithmic_bytes_per_record": alg,
+                         "records_per_launch": n}}
+    from oracle import pyoracle as orc
+    m = min(n, 2048)
+    hf = flows[:m].cpu().numpy().view(np.float32).reshape(m, 4)
+    hg = gyro[:m].cpu().numpy()
+    ref = np.array([orc.derotate(float(hf[i, 0]), float(hf[i, 1]), float(hg[i, 0]), float(hg[i, 1]), float(hg[i, 3]),
+                                 216.6677, 216.2457, 4.5, 0.01) for i in range(m)], dtype=np.float32)
+    line["parity"] = {"oracle_records_bit_exact": bool(np.array_equal(out[:m].cpu().numpy().view(np.uint32),
+                                                                      ref.view(np.uint32))),
+                      "records_checked": m}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,7 +323,7 @@ def main():
     ap.add_argument("--settle-steps", type=int, default=500,
                     help="untimed steps before the warm-up steps (clock settling under sustained load); 0 = off")
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1"])
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1", "derotate"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
     ap.add_argument("--search", default="exhaustive", choices=["exhaustive", "pruned", "strips", "pruned_strips"],
                     help="exhaustive (default, the data-independent rate the metric is quoted on) or "
@@ -321,6 +380,8 @@ def main():
         return bench_ingest(args, aof, device, rank, world, dist)
     if args.workload == "c1":
         return bench_c1(args, aof, rank, world, dist)
+    if args.workload == "derotate":
+        return bench_derotate(args, aof, device, rank, world, dist)
     desc, W, H, over, reach = WORKLOADS[args.workload]
     if args.max_shift is not None:
         reach = args.max_shift
@@ -471,16 +532,7 @@ def main():
     # `traffic` is NOT measured in this run: PMC counters need rocprofv3 around the process.  It is
     # read from the committed summary of the same command under profiles/ (tools/collect_evidence.sh);
     # `traffic_source` names the file, or says that no summary exists for this workload and size.
-    traffic, traffic_source = None, f"none: profiles/pmc_traffic.json has no entry {args.workload}:{n}"
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            ent = json.load(open(tfile)).get(f"{args.workload}:{n}")
-            if ent:
-                traffic = ent["hbm_bytes_per_launch"]
-                traffic_source = ent.get("source", "profiles/pmc_traffic.json")
-        except Exception as e:
-            traffic_source = f"none: profiles/pmc_traffic.json unreadable ({e})"
+    traffic, traffic_source = pmc_traffic(f"{args.workload}:{n}")
     step_ms = elapsed / args.steps * 1e3
     achieved_step = alg_bytes * n / (step_ms * 1e-3) / 1e9   # the whole step (every kernel + gaps), per GPU
 

@@ -1,0 +1,48 @@
+"""`python bench.py --gpus N` must start from a PLAIN command line: with N > 1 and no
+WORLD_SIZE it launches the ranks itself (torch.distributed.run on 127.0.0.1) before anything
+touches a GPU.  The CPU rehearsal (--rendezvous-only) runs the whole N > 1 control flow --
+rendezvous, shard_range, the gather of the 16-byte flow records over gloo, pair order checked
+on every rank -- with placeholder records."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling,pairs,total", [("strong", 7, 7), ("weak", 5, 10), ("strong", 1024, 1024)])
+def test_plain_invocation_spawns_two_ranks(scaling, pairs, total):
+    j = run_bench("--gpus", "2", "--rendezvous-only", "--scaling", scaling, "--pairs", str(pairs))
+    assert j == {"rendezvous_only": True, "n_ranks": 2, "global_pairs": total, "scaling": scaling,
+                 "gathered_in_pair_order_on_every_rank": True}
+
+
+def test_single_rank_needs_no_launcher():
+    j = run_bench("--rendezvous-only", "--pairs", "3")
+    assert j["n_ranks"] == 1 and j["global_pairs"] == 3 and j["gathered_in_pair_order_on_every_rank"]
+
+
+@pytest.mark.gpu
+def test_plain_two_rank_bench_line_on_one_gpu():
+    """The real N = 2 bench path from a plain command line: two ranks share the one GPU of the
+    box (gloo for the gather of the flow records), max-over-ranks timing, one JSON line."""
+    j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--settle-steps", "3",
+                  "--pairs", "8", "--cpu-seconds", "0")
+    assert j["n_gpus"] == 2 and j["config"]["global_pairs"] == 16 and j["steps"] == 2 and j["settle_steps"] == 3
+    assert j["value"] > 0 and j["parity"]["oracle_pairs_bit_exact"] and j["parity"]["all_pairs_return_known_shift"]
+    k = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--settle-steps", "3",
+                  "--pairs", "16", "--scaling", "strong", "--cpu-seconds", "0")
+    assert k["scaling"] == "strong" and k["config"]["global_pairs"] == 16 and k["config"]["pairs_per_gpu"] == 8

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long differential fuzz on a GPU box (not part of the test suite): random geometry, options
-and image statistics; default, strip-kernel, pruned and generic device paths against the CPU oracle.
+and image statistics; default, strip-kernel, pruned, generic and split-coarse device paths against the CPU oracle.
     python tools/fuzz_gpu.py [n_cases] [first_seed]"""
 import importlib
 import os
@@ -78,9 +78,13 @@ def main():
         po = orc.params_from(p)
         refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
         tp, tc = torch.from_numpy(prevs).to(dev), torch.from_numpy(curs).to(dev)
-        for mode in ("exhaustive", "strips", "pruned", "pruned_strips", "generic"):
+        for mode in ("exhaustive", "strips", "pruned", "pruned_strips", "generic", "split"):
+            if mode == "split" and p.pyramid_levels != 2:
+                continue   # (two levels: the coarse passes as separate kernels instead of k_coarse)
             eng = aof.FlowEngine(p, 0)
-            if mode == "generic":
+            if mode == "split":
+                eng.set_split_coarse(True)
+            elif mode == "generic":
                 eng.force_generic(True)
             elif mode == "pruned":
                 eng.set_search_mode(aof.SEARCH_PRUNED)
@@ -105,7 +109,7 @@ def main():
         done += 1
         if done % 25 == 0:
             print(f"{done} cases ok ({time.time() - t0:.0f} s), skipped {skipped}, kernels {variants}", flush=True)
-    print(f"fuzz passed: {done} cases x 5 device paths, {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
+    print(f"fuzz passed: {done} cases x 5 device paths (+ split coarse passes on two-level cases), {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
