@@ -342,6 +342,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0,
                     help="two-level workloads: pairs per pipelined sub-batch (coarse passes of sub-batch i+1 on a "
                          "second stream under the level-0 search of sub-batch i); 0 = off (default), -1 = automatic")
+    ap.add_argument("--coarse", default="auto", choices=["auto", "split"],
+                    help="two-level workloads: how the coarse passes run -- auto (the fused kernel k_coarse where the "
+                         "geometry allows) or split (K1 / level-1 search / K3 as separate kernels)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step's launch sequence into a hipGraph and replay it per step")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -397,6 +400,8 @@ def main():
     if args.force_generic:
         eng.force_generic(True)
     eng.set_pipeline(args.pipeline)
+    if args.coarse != "auto":
+        eng.set_split_coarse(True)
     if args.scaling == "strong":
         sb, se = batch.shard_range(args.pairs, rank, world)
         n = se - sb
@@ -545,7 +550,7 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_gpu": n, "global_pairs": world * n,
-                   "search_kernel": eng.variant, "search": args.search, "k2_launches_per_step": lps, "noise_lsb": args.noise, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
+                   "search_kernel": eng.variant, "search": args.search, "coarse": args.coarse, "k2_launches_per_step": lps, "noise_lsb": args.noise, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
