@@ -118,6 +118,26 @@ __device__ __forceinline__ void wave_vote(uint32_t *hist, int bin, bool active)
     }
 }
 
+// Two histograms at once (the x and y votes of one block): lanes with the same (bin_x, bin_y) pair
+// are joined, one leader adds their count to both histograms -- one loop instead of two, and under a
+// global motion one trip.
+__device__ __forceinline__ void wave_vote2(uint32_t *hist_x, uint32_t *hist_y, int bin_x, int bin_y, bool active)
+{
+    const int key = bin_x | (bin_y << 16);
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader, 64);
+        const unsigned long long same = __ballot(active && key == k) & todo;
+        if ((int)(threadIdx.x & 63) == leader) {
+            const uint32_t c = (uint32_t)__popcll(same);
+            atomicAdd(&hist_x[k & 0xFFFF], c);
+            atomicAdd(&hist_y[k >> 16], c);
+        }
+        todo &= ~same;
+    }
+}
+
 // Bijective XCD-aware remap of a 1-D grid (workgroups b and b+8 share an XCD's
 // L2 under round-robin placement): XCD k gets one contiguous chunk of logical
 // ids, so consecutive strips of one frame pair are staged through the same L2.

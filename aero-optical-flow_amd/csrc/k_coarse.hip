@@ -286,8 +286,7 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
             }
             out[blk] = __builtin_bit_cast(uint32_t, rec);
         }
-        wave_vote(hist, 2 * rec.dx + centre, ok);
-        wave_vote(hist + kMaxBins, 2 * rec.dy + centre, ok);
+        wave_vote2(hist, hist + kMaxBins, 2 * rec.dx + centre, 2 * rec.dy + centre, ok);
         if (ok) { s2x += 2 * rec.dx; s2y += 2 * rec.dy; cnt++; }
     }
     s2x = (int)wave_sum_u32((uint32_t)s2x);

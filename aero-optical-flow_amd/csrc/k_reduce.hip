@@ -72,8 +72,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
             hy = (sd == 1 || sd == 2 || sd == 3) ? 1 : ((sd == 5 || sd == 6 || sd == 7) ? -1 : 0);
         }
         const int vx = 2 * r.dx + hx, vy = 2 * r.dy + hy;
-        wave_vote(hist[0], vx + centre, ok);
-        wave_vote(hist[1], vy + centre, ok);
+        wave_vote2(hist[0], hist[1], vx + centre, vy + centre, ok);
         if (ok) { s2x += vx; s2y += vy; cnt++; }
     };
     for (int it0 = 0; it0 < rounds; it0 += kBatch) {

@@ -417,8 +417,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_flow_lane8(SearchArgs a, FlowTa
     const bool ok = live && (uint32_t)rec.sad < (uint32_t)a.value_threshold;  // skipped = 0xFFFF
     const int hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
     const int hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
-    wave_vote(s_votes, p * 2 * n + 2 * rec.dx + hx + centre, ok);
-    wave_vote(s_votes, p * 2 * n + n + 2 * rec.dy + hy + centre, ok);
+    wave_vote2(s_votes, s_votes, p * 2 * n + 2 * rec.dx + hx + centre, p * 2 * n + n + 2 * rec.dy + hy + centre, ok);
     __syncthreads();
     if (tid < np) {
         const uint32_t *hxp = s_votes + tid * 2 * n, *hyp = hxp + n;
