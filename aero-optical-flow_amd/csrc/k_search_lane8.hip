@@ -218,6 +218,28 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
     // following pair correct it: a per-lane load here would be a whole memory round trip in front
     // of the 24 row loads, and a per-lane 64-bit base address costs two VALU per row.
     const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair);
+    // Row loads through buffer resources: the descriptor (base of the wave's first pair) and the
+    // row offset r*W live in scalar registers, the lane contributes ONE 32-bit byte offset -- no
+    // VALU per row.  Reads past the last pair's frame return zero instead of faulting.
+    const uint64_t span = a.n_pairs > 1 ? (uint64_t)(a.n_pairs - first) * (uint64_t)a.pair_stride
+                                        : (uint64_t)a.w * (uint64_t)a.h;
+    const uint32_t records = span > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)span;
+    const int64_t base = (int64_t)first * a.pair_stride;
+    const __amdgpu_buffer_rsrc_t rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.prev) + base, 0, records, kRawBuffer);
+    const __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.cur) + base, 0, records, kRawBuffer);
+    const uint32_t dp = (pair - first) * (uint32_t)a.pair_stride;   // lane8_supported: fits 32 bits
+    const uint32_t off_prev = dp + (uint32_t)(__mul24(j, W) + i);
+    // The reference tile does not depend on the predictor: its eight rows are requested before the
+    // scalar loads of predictor and pixel sums have come back (the tile of a grid block always lies
+    // inside the frame).
+    uint32_t ref[8][2];
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_prev, off_prev, r * W, 0);
+            ref[r][0] = v.x; ref[r][1] = v.y;
+        }
+    }
     typedef const __attribute__((address_space(4))) uint32_t *const_u32;  // read-only during the kernel
     const uint32_t npix = (uint32_t)(a.w * a.h);
     if (EQ && a.sums) {   // (outside the lane-dependent branch: stays in scalar registers)
@@ -247,27 +269,10 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
         }
         return 8;
     }
-    // Row loads through buffer resources: the descriptor (base of the wave's first pair) and the
-    // row offset r*W live in scalar registers, the lane contributes ONE 32-bit byte offset -- no
-    // VALU per row.  Reads past the last pair's frame return zero instead of faulting.
-    const uint64_t span = a.n_pairs > 1 ? (uint64_t)(a.n_pairs - first) * (uint64_t)a.pair_stride
-                                        : (uint64_t)a.w * (uint64_t)a.h;
-    const uint32_t records = span > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)span;
-    const int64_t base = (int64_t)first * a.pair_stride;
-    const __amdgpu_buffer_rsrc_t rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.prev) + base, 0, records, kRawBuffer);
-    const __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.cur) + base, 0, records, kRawBuffer);
-    const uint32_t dp = (pair - first) * (uint32_t)a.pair_stride;   // lane8_supported: fits 32 bits
-    const uint32_t off_prev = dp + (uint32_t)(__mul24(j, W) + i);
     const uint32_t off_cur = dp + (uint32_t)(__mul24(wy0, W) + wx0);
 
-    uint32_t ref[8][2];
     uint4 win[16];
     if (inside) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_prev, off_prev, r * W, 0);
-            ref[r][0] = v.x; ref[r][1] = v.y;
-        }
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off_cur, s * W, 0);

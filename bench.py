@@ -257,14 +257,15 @@ def bench_ingest(args, aof, device, rank, world, dist):
         dist.destroy_process_group()
 
 
-def pmc_traffic(key):
-    """HBM bytes per launch from the committed PMC summary of the same command (profiles/), and its source."""
+def pmc_traffic(key, field="hbm_bytes_per_launch"):
+    """HBM bytes per launch from the committed PMC summary of the same command (profiles/), and its source.
+    field "step_bytes": all kernels of one step instead of the dominant kernel alone."""
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
         try:
             ent = json.load(open(tfile)).get(key)
-            if ent:
-                return ent["hbm_bytes_per_launch"], ent.get("source", "profiles/pmc_traffic.json")
+            if ent and field in ent:
+                return ent[field], ent.get("source", "profiles/pmc_traffic.json")
         except Exception as e:
             return None, f"none: profiles/pmc_traffic.json unreadable ({e})"
     return None, f"none: profiles/pmc_traffic.json has no entry {key}"
@@ -555,6 +556,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": traffic_source,
+                     # beyond-L2 bytes of ALL kernels of one step (same source): what to hold against the
+                     # algorithmic bytes of a multi-kernel workload
+                     "traffic_step": pmc_traffic(f"{args.workload}:{n}", "step_bytes")[0],
                      # the same algorithmic bytes over the WHOLE step (all kernels of the workload and
                      # the gaps between them): the figure to quote for multi-kernel workloads (c3, c5p)
                      "achieved_step": round(achieved_step, 1), "frac_step": round(achieved_step / HBM_PEAK_GBS, 4),

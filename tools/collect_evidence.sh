@@ -8,17 +8,17 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/evidence
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-WL=${@:-c2 c3 c5 c2h c1b ingest derotate}
+WL=${@:-c2 c3 c5 c2h c1b c5h ingest derotate}
 args_of() {   # bench.py arguments and the launch size key of a workload
     case $1 in
-        c5) echo "--pairs 256";;
+        c5|c5h) echo "--pairs 256";;
         c1b) echo "--pairs 65536";;
         ingest) echo "--pairs 1024";;
         derotate) echo "--pairs 1024";;
         *) echo "";;
     esac
 }
-key_of() { case $1 in c5) echo 256;; c1b) echo 65536;; ingest) echo 8192;; derotate) echo 1048576;; *) echo 1024;; esac; }
+key_of() { case $1 in c5|c5h) echo 256;; c1b) echo 65536;; ingest) echo 8192;; derotate) echo 1048576;; *) echo 1024;; esac; }
 for wl in $WL; do
     extra=$(args_of $wl)
     timeout -k 10 300 python3 $R/bench.py --workload $wl $extra > $O/bench_$wl.json 2> $O/bench_$wl.err || { echo "bench $wl failed"; tail -3 $O/bench_$wl.err; exit 1; }

@@ -55,8 +55,13 @@ def main():
         rd, wr = traffic[search[0]]
         path = os.path.join(os.path.dirname(os.path.abspath(out_txt)), "pmc_traffic.json")
         data = json.load(open(path)) if os.path.exists(path) else {}
+        # every kernel of one step (the opt-in pruned variants bench.py also runs are not part of it);
+        # a kernel name that serves two launches per step (split coarse path) counts once, at its larger launch
+        step = {k: v for k, v in traffic.items() if not k.endswith(", true>") and "_pruned" not in k}
         data[f"{workload}:{pairs}"] = {"kernel": search[0], "hbm_bytes_per_launch": int(rd + wr),
                                        "read_bytes": int(rd), "write_bytes": int(wr),
+                                       "step_bytes": int(sum(a + b for a, b in step.values())),
+                                       "step_kernels": sorted(step),
                                        "source": os.path.basename(out_txt)}
         json.dump(data, open(path, "w"), indent=1, sort_keys=True)
 
