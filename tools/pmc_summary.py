@@ -47,7 +47,9 @@ def main():
     # the level-0 search is the k_search kernel that moves the most bytes
     # (bench.py also runs the opt-in pruned search, template argument PRUNE = true: not the headline)
     names = [k for k in traffic if k.startswith("k_search") or k.startswith("k_flow")]
-    names = [k for k in names if not k.endswith(", true>") and "_pruned" not in k] or names
+    def pruned(k):   # the opt-in exact-pruned variants bench.py also runs: not part of the headline step
+        return "_pruned" in k or k == "k_search_tile16<true>"
+    names = [k for k in names if not pruned(k)] or names
     if not names:   # workloads without a search kernel (ingest, derotate): the kernel that moves the most bytes
         names = list(traffic)
     search = sorted(names, key=lambda k: -sum(traffic[k]))
@@ -57,7 +59,7 @@ def main():
         data = json.load(open(path)) if os.path.exists(path) else {}
         # every kernel of one step (the opt-in pruned variants bench.py also runs are not part of it);
         # a kernel name that serves two launches per step (split coarse path) counts once, at its larger launch
-        step = {k: v for k, v in traffic.items() if not k.endswith(", true>") and "_pruned" not in k}
+        step = {k: v for k, v in traffic.items() if not pruned(k)}
         data[f"{workload}:{pairs}"] = {"kernel": search[0], "hbm_bytes_per_launch": int(rd + wr),
                                        "read_bytes": int(rd), "write_bytes": int(wr),
                                        "step_bytes": int(sum(a + b for a, b in step.values())),
