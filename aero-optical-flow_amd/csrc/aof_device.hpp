@@ -118,24 +118,27 @@ __device__ __forceinline__ void wave_vote(uint32_t *hist, int bin, bool active)
     }
 }
 
-// Two histograms at once (the x and y votes of one block): lanes with the same (bin_x, bin_y) pair
-// are joined, one leader adds their count to both histograms -- one loop instead of two, and under a
-// global motion one trip.
+// Two histograms at once (the x and y votes of one block).  Under a global motion every lane of the
+// wave votes for the same (bin_x, bin_y) pair: one ballot, one leader, two adds.  Otherwise the two
+// axes are voted separately -- at most as many trips as there are distinct bins per axis (joint
+// (x, y) keys would need up to their product on unrelated frames).
 __device__ __forceinline__ void wave_vote2(uint32_t *hist_x, uint32_t *hist_y, int bin_x, int bin_y, bool active)
 {
+    const unsigned long long todo = __ballot(active);
+    if (todo == 0) return;
     const int key = bin_x | (bin_y << 16);
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int k = __shfl(key, leader, 64);
-        const unsigned long long same = __ballot(active && key == k) & todo;
+    const int leader = __ffsll((long long)todo) - 1;
+    const int k = __shfl(key, leader, 64);
+    if ((__ballot(active && key == k) & todo) == todo) {   // (wave-uniform)
         if ((int)(threadIdx.x & 63) == leader) {
-            const uint32_t c = (uint32_t)__popcll(same);
+            const uint32_t c = (uint32_t)__popcll(todo);
             atomicAdd(&hist_x[k & 0xFFFF], c);
             atomicAdd(&hist_y[k >> 16], c);
         }
-        todo &= ~same;
+        return;
     }
+    wave_vote(hist_x, bin_x, active);
+    wave_vote(hist_y, bin_y, active);
 }
 
 // Bijective XCD-aware remap of a 1-D grid (workgroups b and b+8 share an XCD's

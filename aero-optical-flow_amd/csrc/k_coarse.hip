@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
     }
     lds_barrier();
     LAB_STAMP(4);
-    if (tid == 0) finalise_flow(a.tail, pair, hist, hist + kMaxBins, vs);
+    if (tid < 64) finalise_flow_wave(a.tail, pair, hist, hist + kMaxBins, vs);   // (kMaxBins = 64 bins at most)
     LAB_STAMP(5);
     (void)n;
     lds_barrier();   // lane 0 still reads the histograms the next pair's first step clears

@@ -107,7 +107,11 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
     }
     sync();
     }
-    if (tid == 0) finalise_flow(a.tail, pair, hist[0], hist[1], sums);
+    if (n <= 64) {   // (uniform) one wave of the group: the bins side by side
+        if (tid < 64) finalise_flow_wave(a.tail, pair, hist[0], hist[1], sums);
+    } else if (tid == 0) {
+        finalise_flow(a.tail, pair, hist[0], hist[1], sums);
+    }
 }
 
 // Large grids (a 4K frame has 128 000 blocks): one workgroup per chunk of 4 096 records votes
