@@ -6,6 +6,11 @@
  * tests or golden vectors).  Every function restates the published PX4Flow
  * algorithm (ICRA 2013) or a build-defined extension from DESIGN.md "Spec";
  * the reference anchors are the call sites in /root/reference/src/mainloop.cpp.
+ * There is NO upstream commit this file was transcribed against: PX4/OpticalFlow (branch
+ * static_lib, /root/reference/.gitmodules:1-4) was never readable here; what pins it instead
+ * are analytic known answers and the hand-derived end-to-end vectors of
+ * tests/test_hand_vectors.py, whose expectations are literals written down from the construction
+ * of the frames (the oracle on CPU and the HIP path on the GPU are held to the same numbers).
  *
  * Written for clarity, not speed: plain loops, no intrinsics.
  */

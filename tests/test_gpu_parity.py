@@ -940,6 +940,30 @@ def test_streaming_graph_and_eager_paths_agree(aof, orc, synth, gpu_device, kw):
         assert outs[0][k - 1] == orc.flow_pair(po, frames[k - 1], frames[k])["flow"].tobytes()
 
 
+def test_streaming_path_follows_kernel_switches_mid_sequence(aof, orc, synth, gpu_device):
+    """The streaming entry point replays captured hipGraphs: switching the kernel selection
+    (aof_set_force_generic, aof_set_search_mode, aof_set_split_coarse) between two frames must
+    drop them, so that the next frame really runs the newly selected kernels -- and of course all
+    of them give the oracle's record."""
+    p = aof.default_params(160, 128, pyramid_levels=2, mean_subtract=1)
+    frames, _ = synth.make_sequence(p.width, p.height, 14, 6, seed=33, max_step=5)
+    po = orc.params_from(p)
+    eng = aof.FlowEngine(p, 0)
+    assert eng.stream_push(frames[0]) is None
+    switches = {3: lambda: eng.force_generic(True), 5: lambda: eng.force_generic(False),
+                7: lambda: eng.set_search_mode(aof.SEARCH_PRUNED), 9: lambda: eng.set_split_coarse(True),
+                11: lambda: (eng.set_split_coarse(False), eng.set_search_mode(aof.SEARCH_EXHAUSTIVE))}
+    for k in range(1, 14):
+        if k in switches:
+            was_active = eng.stream_graph_active()
+            switches[k]()
+            assert was_active and not eng.stream_graph_active(), "a kernel switch must drop the captured graphs"
+            assert eng.variant == ("generic" if 3 <= k < 5 else "lane8")
+        got = eng.stream_push(frames[k])
+        assert got.tobytes() == orc.flow_pair(po, frames[k - 1], frames[k])["flow"].tobytes(), k
+    eng.close()
+
+
 def test_c_abi_argument_handling(aof, orc, synth, gpu_device):
     """Direct calls into the C ABI: optional outputs, error codes, many small pairs."""
     import ctypes as C
