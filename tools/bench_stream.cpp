@@ -8,8 +8,10 @@
 int main(int argc, char **argv)
 {
     const int w = argc > 1 ? atoi(argv[1]) : 64, h = argc > 2 ? atoi(argv[2]) : 64, calls = 5000;
+    const int levels = argc > 3 ? atoi(argv[3]) : 1;   // 2: what OpticalFlowOpenCV ships (two levels + mean equalisation)
     aof_params p;
     aof_params_px4flow(&p, w, h, 4, 30, 3000);
+    if (levels == 2) { p.pyramid_levels = 2; p.mean_subtract = 1; }
     std::vector<uint8_t> f[2];
     // a blurred random canvas cropped twice, 2 px / 1 px apart: every block has a clear match
     std::vector<int> canvas((size_t)(w + 8) * (h + 8));
@@ -35,7 +37,7 @@ int main(int argc, char **argv)
         auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < calls; i++) aof_stream_push_host(ctx, f[i & 1].data(), &out);
         double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
-        printf("%dx%d %s graph=%d instantiated=%d: %.2f us per call (quality %d)\n", w, h,
+        printf("%dx%d levels=%d %s graph=%d instantiated=%d: %.2f us per call (quality %d)\n", w, h, levels,
                aof_search_variant(ctx), graph, aof_set_stream_graph(ctx, -1), us, out.quality);
         aof_destroy(ctx);
     }
