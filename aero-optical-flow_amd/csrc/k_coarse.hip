@@ -364,12 +364,10 @@ int launch_coarse_fused(const CoarseArgs &a, void *stream)
         k.stagger_ticks = (int32_t)((int64_t)2 * a.w * a.h * 100 / kStaggerBytesPerUs);
     }
     const size_t lds = coarse_lds_bytes(a);
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // (per launch, like the 16x16 kernel: the attribute belongs to the current device's code object)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     // one workgroup per CU (LDS); each walks pairs blockIdx.x, blockIdx.x + gridDim.x, ...
     const int64_t wgs = a.n_pairs < k.first_generation ? a.n_pairs : k.first_generation;
