@@ -131,6 +131,8 @@ SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const
     return a;
 }
 
+constexpr int64_t kSmallMaxPairs = 128;   // one-launch path for small pairs: measured faster than the separate kernels up to here
+
 enum SearchKind { SK_TILE8, SK_TILE16, SK_LANE8_GROUP, SK_LANE8, SK_GENERIC };
 
 // Which search kernel serves these arguments (run_search, enqueue_level and aof_search_variant agree).
@@ -506,6 +508,27 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
     if (p.subpixel) v.subdirs0 = d_subdirs ? d_subdirs : ws + L.l0_subdirs;
     v.flows = d_flows;
     v.hist0 = ws + L.l0_hist;
+
+    // Small pairs (sparse grids, frames that fit LDS -- the reference's call shape): sums, pyramid,
+    // searches and reductions of a pair in one launch, one workgroup per pair.  Large batches of
+    // such pairs keep the separate kernels, whose grouped searches pack several pairs into a workgroup.
+    if (!ctx->force_generic && !ctx->split_coarse && n_pairs <= kSmallMaxPairs) {
+        SmallArgs sm;
+        sm.levels = two ? 2 : 1;
+        sm.l0 = search_args(ctx, 0, v.prev, v.cur, v.stride, v.blocks0, v.subdirs0, nullptr, v.sums, n_pairs);
+        sm.l1 = search_args(ctx, 1, v.l1_prev, v.l1_cur, (int64_t)(p.width / 2) * (p.height / 2), v.blocks1, v.subdirs1,
+                            nullptr, v.sums, n_pairs);
+        sm.t0 = flow_tail(ctx, 0, v.flows, two ? v.flows1 : nullptr);
+        sm.t1 = flow_tail(ctx, 1, v.flows1, nullptr);
+        sm.sums = v.sums;
+        if (search_kind(ctx, sm.l0) == SK_LANE8_GROUP && (!two || search_kind(ctx, sm.l1) == SK_LANE8_GROUP) &&
+            flow_small_supported(sm)) {
+            Timed t(ctx, AOF_K_SEARCH, s);
+            rc = launch_flow_small(sm, s);
+            if (rc) return fail(ctx, -EIO, "small-pair launch: %s", hipGetErrorString((hipError_t)rc));
+            return 0;
+        }
+    }
 
     // Two levels: the coarse passes are HBM-bound (K1 streams both frames) and the level-0
     // search is VALU-bound, so a large batch is cut into sub-batches and the coarse passes of

@@ -78,6 +78,15 @@ __device__ __forceinline__ uint4 sat_add_u8x16(uint4 v, int delta)
     return v;
 }
 
+// 2x2 box filter (a+b+c+d+2)>>2: two level-1 pixels from one dword of each of two rows, returned in
+// bytes 0 and 2.
+__device__ __forceinline__ uint32_t box2(uint32_t a, uint32_t b)
+{
+    const uint32_t m = 0x00FF00FFu;
+    const uint32_t s = (a & m) + ((a >> 8) & m) + (b & m) + ((b >> 8) & m) + 0x00020002u;
+    return (s >> 2) & m;
+}
+
 // Sum of the four bytes of w added to acc (v_sad_u8 against zero).
 __device__ __forceinline__ uint32_t byte_sum(uint32_t w, uint32_t acc)
 {

@@ -49,8 +49,8 @@ bool tile8_geometry(const aof_params &p, int level);  // level can run the tile8
 int grid_for_level(const aof_params &p, int level, Grid *g);
 int level_range(const aof_params &p, int level);  // histogram half-range R
 int value_threshold_u16(const aof_params &p);     // SAD gate clamped to the u16 record
-int reduce_chunks(int nblocks);
-size_t hist_bytes_per_pair(const aof_params &p, int level);  // vote-histogram scratch of one pair                   // 0: one reduction workgroup per pair reads all records
+int reduce_chunks(int nblocks);                   // 0: one reduction workgroup per pair reads all records
+size_t hist_bytes_per_pair(const aof_params &p, int level);  // vote-histogram scratch of one pair
 
 // What turns a pair's vote histograms into its aof_flow (K3).
 struct FlowTail {
@@ -116,6 +116,17 @@ struct CoarseArgs {
     int32_t rows_per_sweep;    // launcher: level-1 rows one sweep of the workgroup's lanes covers
 };
 
+// The one-workgroup kernel for small pairs (k_flow_small): one or two levels of a pair whose frames
+// fit LDS and whose grids have at most 256 blocks each.  Reads l0.prev / l0.cur only; l1.prev,
+// l1.cur, the pred and sums pointers inside l0 / l1 are not used (level-1 frames, predictor and
+// deltas stay on chip).
+struct SmallArgs {
+    SearchArgs l0, l1;         // l1 only for levels == 2
+    FlowTail t0, t1;
+    uint32_t *sums;            // [n_pairs][2][2] written here, or nullptr when not equalising
+    int32_t levels;
+};
+
 struct PyramidArgs {
     const uint8_t *prev, *cur;
     int64_t pair_stride;
@@ -149,6 +160,9 @@ int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream);
 // LDS-tiled (block, dy)-per-lane kernel for B=16, S=8 on a dense grid (any predictor).
 bool tile16_supported(const SearchArgs &a);
 int launch_search_tile16(const SearchArgs &a, void *stream);
+// Small pairs (frames fit LDS, grids <= 256 blocks), one or two levels, in one launch: one workgroup per pair.
+bool flow_small_supported(const SmallArgs &a);
+int launch_flow_small(const SmallArgs &a, void *stream);
 int launch_reduce(const ReduceArgs &a, void *stream);
 int launch_derotate(const aof_derotate_params &p, const aof_flow *flows, const aof_gyro *gyro,
                     int64_t n, float *out, void *stream);

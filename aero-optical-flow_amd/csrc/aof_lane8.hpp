@@ -1,0 +1,351 @@
+// The lane-per-block 8x8 search shared by the flat and grouped kernels (k_search_lane8.hip) and by
+// the one-workgroup two-level kernel (k_flow_small.hip): all 81 candidates of one block in one lane
+// (DESIGN.md "Kernels": K2).
+#pragma once
+
+#include "aof_device.hpp"
+#include "aof_internal.hpp"
+#include "aof_refine.hpp"
+
+namespace aof {
+
+namespace {
+
+__device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
+{
+    return __builtin_amdgcn_qsad_pk_u16_u8(window, ref, acc);
+}
+__device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | lo; }
+
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t x, uint32_t y)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, x),
+                                                                  __builtin_bit_cast(ushort2_t, y)));
+}
+
+// 4x4 gradient gate on tile bytes [2..5] x rows [2..5]
+__device__ __forceinline__ uint32_t gradient_gate(const uint32_t (&ref)[8][2])
+{
+    uint32_t mid[4], diff = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) mid[r] = __builtin_amdgcn_alignbyte(ref[r + 2][1], ref[r + 2][0], 2);
+#pragma unroll
+    for (int r = 0; r < 3; r++) diff = __builtin_amdgcn_sad_u8(mid[r], mid[r + 1], diff);
+#pragma unroll
+    for (int r = 0; r < 4; r++)  // bytes (3,4,5,5) against (2,3,4,5): the doubled byte adds 0
+        diff = __builtin_amdgcn_sad_u8(mid[r], __builtin_amdgcn_perm(0u, mid[r], 0x03030201u), diff);
+    return diff;
+}
+
+// All 81 candidates: per dy, offsets 0..3 / 4..7 as packed u16, offset 8 as (sad << 16 | idx);
+// returns the smallest packed key = first minimum in scan order.
+template <bool EQUALISE>
+__device__ __forceinline__ uint32_t exhaustive_search(const uint4 (&win)[16], const uint32_t (&ref)[8][2], int delta)
+{
+    u64 acc_lo[9], acc_hi[9];
+    uint32_t acc_8[9];
+#pragma unroll
+    for (int d = 0; d < 9; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)(d * 9 + 8); }
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        uint4 w = win[s];
+        if (EQUALISE && delta != 0) w = sat_add_u8x16(w, delta);
+        const u64 p01 = pack64(w.x, w.y), p12 = pack64(w.y, w.z), p23 = pack64(w.z, w.w);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int d = s - r;  // dy index, dy = d - 4
+            if (d < 0 || d >= 9) continue;
+            acc_lo[d] = qsad(p01, ref[r][0], acc_lo[d]);
+            acc_lo[d] = qsad(p12, ref[r][1], acc_lo[d]);
+            acc_hi[d] = qsad(p12, ref[r][0], acc_hi[d]);
+            acc_hi[d] = qsad(p23, ref[r][1], acc_hi[d]);
+            acc_8[d] = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], acc_8[d]);
+            acc_8[d] = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], acc_8[d]);
+        }
+    }
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 0; d < 9; d++) {
+        const uint32_t base = (uint32_t)(d * 9);
+        const uint32_t l0 = (uint32_t)acc_lo[d], l1 = (uint32_t)(acc_lo[d] >> 32);
+        const uint32_t h0 = (uint32_t)acc_hi[d], h1 = (uint32_t)(acc_hi[d] >> 32);
+        const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
+        const uint32_t k2 = (l1 << 16) | (base + 2), k3 = (l1 & 0xFFFF0000u) | (base + 3);
+        const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
+        const uint32_t k6 = (h1 << 16) | (base + 6), k7 = (h1 & 0xFFFF0000u) | (base + 7);
+        best = min(best, min(min(k0, k1), k2));
+        best = min(best, min(min(k3, k4), k5));
+        best = min(best, min(min(k6, k7), acc_8[d]));
+    }
+    return best;
+}
+
+// One dy row (compile-time index D, so the window rows are plain registers) of the exact
+// pruned search: a partial SAD only grows, so when after two (then four) of the eight row pairs
+// no lane of the wave that still needs a result can beat or tie its best, the row is dropped for
+// the whole wave.  Returns false when the row was dropped.
+template <int D>
+__device__ __forceinline__ bool pruned_row(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+                                           uint32_t &best)
+{
+    u64 alo[2] = {0, 0}, ahi[2] = {0, 0};
+    uint32_t a8[2] = {(uint32_t)(D * 9 + 8), 0u};
+    auto row_pair = [&](int r, int set) {
+        const uint4 w = win[D + r];
+        const u64 p01 = pack64(w.x, w.y), p12 = pack64(w.y, w.z), p23 = pack64(w.z, w.w);
+        alo[set] = qsad(p01, ref[r][0], alo[set]);
+        ahi[set] = qsad(p12, ref[r][0], ahi[set]);
+        alo[set] = qsad(p12, ref[r][1], alo[set]);
+        ahi[set] = qsad(p23, ref[r][1], ahi[set]);
+        a8[set] = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], a8[set]);
+        a8[set] = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], a8[set]);
+    };
+    auto partial_min = [&]() -> uint32_t {  // <= 32 pixels per field: no carry between the u16 fields
+        const uint32_t s0 = (uint32_t)alo[0] + (uint32_t)alo[1], s1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
+        const uint32_t s2 = (uint32_t)ahi[0] + (uint32_t)ahi[1], s3 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
+        const uint32_t m = pk_min_u16(pk_min_u16(s0, s1), pk_min_u16(s2, s3));
+        return min(min(m & 0xFFFFu, m >> 16), (a8[0] + a8[1]) >> 16);
+    };
+    row_pair(0, 0);
+    row_pair(4, 1);
+    if (__ballot(need && partial_min() <= (best >> 16)) == 0) return false;
+    row_pair(2, 0);
+    row_pair(6, 1);
+    if (__ballot(need && partial_min() <= (best >> 16)) == 0) return false;
+    row_pair(1, 1);
+    row_pair(3, 0);
+    row_pair(5, 1);
+    row_pair(7, 0);
+    const uint32_t l0 = (uint32_t)alo[0] + (uint32_t)alo[1], l1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
+    const uint32_t h0 = (uint32_t)ahi[0] + (uint32_t)ahi[1], h1 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
+    const uint32_t base = (uint32_t)(D * 9);
+    const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
+    const uint32_t k2 = (l1 << 16) | (base + 2), k3 = (l1 & 0xFFFF0000u) | (base + 3);
+    const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
+    const uint32_t k6 = (h1 << 16) | (base + 6), k7 = (h1 & 0xFFFF0000u) | (base + 7);
+    best = min(best, min(min(k0, k1), k2));
+    best = min(best, min(min(k3, k4), k5));
+    best = min(best, min(min(k6, k7), a8[0] + a8[1]));
+    return true;
+}
+
+// The k-th row of the visiting order start, start-1, start+1, start-2, ... (whichever side is
+// still in range), closed form.
+constexpr int visit_order(int start, int k)
+{
+    if (k == 0) return start;
+    const int below = start, above = 8 - start;
+    const int pairs = below < above ? below : above;
+    if (k <= 2 * pairs) return (k & 1) ? start - (k + 1) / 2 : start + k / 2;
+    return below > above ? start - pairs - (k - 2 * pairs) : start + pairs + (k - 2 * pairs);
+}
+
+// All nine rows from a compile-time start row: straight-line code, every window row a plain
+// register (a run-time row index would push the 64-register window into scratch).
+template <int START, int K = 0>
+__device__ __forceinline__ int pruned_from(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+                                           uint32_t &best)
+{
+    const int dropped = pruned_row<visit_order(START, K)>(win, ref, need, best) ? 0 : 1;
+    if constexpr (K < 8) return dropped + pruned_from<START, K + 1>(win, ref, need, best);
+    else return dropped;
+}
+
+// The nine dy rows in the order start, start-1, start+1, ... (start is wave-uniform): one
+// specialised copy of the row sequence per start row; returns how many rows were dropped.
+__device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+                                             int start, uint32_t &best)
+{
+    switch (start) {
+    case 0: return pruned_from<0>(win, ref, need, best);
+    case 1: return pruned_from<1>(win, ref, need, best);
+    case 2: return pruned_from<2>(win, ref, need, best);
+    case 3: return pruned_from<3>(win, ref, need, best);
+    case 4: return pruned_from<4>(win, ref, need, best);
+    case 5: return pruned_from<5>(win, ref, need, best);
+    case 6: return pruned_from<6>(win, ref, need, best);
+    case 7: return pruned_from<7>(win, ref, need, best);
+    default: return pruned_from<8>(win, ref, need, best);
+    }
+}
+
+// One block: record (and direction) written to global memory and returned for the votes.
+// Returns the half-pixel direction (8 = none).  PRUNE: the wave-uniform exact pruned search;
+// start_row / prune_pays are the wave's hints carried from its previous chunk of blocks (every
+// lane of the wave stays in the control flow until the search is over, so ballots see them all).
+// EQ = false: the launch has no pixel sums (a.sums == nullptr): no equalisation code at all in the
+// kernel (the exhaustive flat kernel is instantiated both ways; its code size and register
+// allocation are what the headline configuration runs on).
+// `given`: predictor and equalisation delta handed over by the caller (a kernel that has just
+// computed them itself and must not read them back through the constant cache); a.pred and a.sums
+// are then not read.
+struct PairMeta { int px, py, delta; };
+
+template <bool SUBPIXEL, bool PRUNE, bool EQ = true>
+__device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, uint32_t blk, uint32_t item, bool live,
+                                            aof_block &rec, int &start_row, int &prune_pays,
+                                            const PairMeta *given = nullptr)
+{
+    // (blocks, grid coordinates and pixel offsets stay below 2^24 -- aof_params_check limits a frame to
+    //  2^24 pixels --, so the products are full-rate 24-bit multiplies, not quarter-rate 32-bit ones)
+    const uint32_t by = fast_div(blk, a.div_nx), bx = blk - __umul24(by, (uint32_t)a.grid.nx);
+    const int i = a.grid.x0 + __mul24((int)bx, a.grid.step_x), j = a.grid.y0 + __mul24((int)by, a.grid.step_y);
+    const int W = a.w;
+    constexpr int m = SUBPIXEL ? 1 : 0;
+    int px = 0, py = 0, delta = 0, delta_first = 0;
+    // Almost every wave lies inside one pair.  Everything that depends on the pair alone is
+    // computed for the wave's FIRST pair in scalar registers -- frame base addresses, predictor,
+    // equalisation delta (scalar loads, served by the constant cache) -- and only the lanes of a
+    // following pair correct it: a per-lane load here would be a whole memory round trip in front
+    // of the 24 row loads, and a per-lane 64-bit base address costs two VALU per row.
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair);
+    // Row loads through buffer resources: the descriptor (base of the wave's first pair) and the
+    // row offset r*W live in scalar registers, the lane contributes ONE 32-bit byte offset -- no
+    // VALU per row.  Reads past the last pair's frame return zero instead of faulting.
+    const uint64_t span = a.n_pairs > 1 ? (uint64_t)(a.n_pairs - first) * (uint64_t)a.pair_stride
+                                        : (uint64_t)a.w * (uint64_t)a.h;
+    const uint32_t records = span > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)span;
+    const int64_t base = (int64_t)first * a.pair_stride;
+    const __amdgpu_buffer_rsrc_t rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.prev) + base, 0, records, kRawBuffer);
+    const __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.cur) + base, 0, records, kRawBuffer);
+    const uint32_t dp = (pair - first) * (uint32_t)a.pair_stride;   // lane8_supported: fits 32 bits
+    const uint32_t off_prev = dp + (uint32_t)(__mul24(j, W) + i);
+    // The reference tile does not depend on the predictor: its eight rows are requested before the
+    // scalar loads of predictor and pixel sums have come back (the tile of a grid block always lies
+    // inside the frame).
+    uint32_t ref[8][2];
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_prev, off_prev, r * W, 0);
+            ref[r][0] = v.x; ref[r][1] = v.y;
+        }
+    }
+    typedef const __attribute__((address_space(4))) uint32_t *const_u32;  // read-only during the kernel
+    const uint32_t npix = (uint32_t)(a.w * a.h);
+    if (EQ && a.sums && !given) {   // (outside the lane-dependent branch: stays in scalar registers)
+        const const_u32 sm = (const_u32)(a.sums + (size_t)first * 4);
+        delta_first = (int)((sm[a.level] + npix / 2) / npix) - (int)((sm[2 + a.level] + npix / 2) / npix);
+    }
+    if (given) {
+        if (live) { px = given->px; py = given->py; delta = given->delta; }
+    } else if (live) {
+        if (a.pred) {
+            const uint32_t w3 = ((const_u32)(a.pred + first))[3];  // quality, flags, pred_x, pred_y
+            px = (int8_t)(w3 >> 16); py = (int8_t)(w3 >> 24);
+            if (pair != first) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
+        }
+        if (EQ && a.sums) {
+            delta = delta_first;
+            if (pair != first) delta = equalise_delta(a.sums, pair, a.level, npix);
+        }
+    }
+    rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.blocks) + item;  // one dword store per record
+    // the search window (plus the half-pixel ring) must lie inside the frame
+    const int wx0 = i + px - 4, wy0 = j + py - 4;
+    const bool inside = live && !(wx0 - m < 0 || wy0 - m < 0 || wx0 + 16 + m > a.w || wy0 + 16 + m > a.h);
+    if (!PRUNE && !inside) {
+        if (live) {
+            *out = __builtin_bit_cast(uint32_t, rec);
+            if (SUBPIXEL) a.subdirs[item] = 8;
+        }
+        return 8;
+    }
+    const uint32_t off_cur = dp + (uint32_t)(__mul24(wy0, W) + wx0);
+
+    uint4 win[16];
+    if (inside) {
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off_cur, s * W, 0);
+            win[s] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    }
+#ifndef AOF_LAB_TWO_TRIPS
+    // ONE memory round trip: left alone, the compiler sinks the window loads (and half of the tile
+    // loads) below the gate's branch, so a wave first waits for four tile rows, gates, and only
+    // then requests the other twenty rows.  Naming the last window row here keeps all 24 loads
+    // in front of the gate (they return in order: one wait for everything).
+    if (inside) asm volatile("" : "+v"(win[15].w));
+#endif
+    uint32_t gradient = 0;
+    if (inside) gradient = gradient_gate(ref);
+    const bool need = inside && gradient >= (uint32_t)a.feature_threshold;
+    if (!PRUNE && !need) {
+        *out = __builtin_bit_cast(uint32_t, rec);
+        if (SUBPIXEL) a.subdirs[item] = 8;
+        return 8;
+    }
+    if (PRUNE && need && delta != 0) {  // the pruned rows read a window row several times
+#pragma unroll
+        for (int s = 0; s < 16; s++) win[s] = sat_add_u8x16(win[s], delta);
+    }
+    uint32_t best = 0xFFFFFFFFu;
+    if constexpr (PRUNE) {
+        const unsigned long long needing = __ballot(need);
+        if (needing != 0) {
+            if (__builtin_amdgcn_readfirstlane(prune_pays) == 0) {
+                // noise-dominated images: the previous chunk of this wave could drop (almost)
+                // nothing, and the exhaustive code is the faster way to evaluate everything
+                if (need) best = exhaustive_search<false>(win, ref, 0);
+            } else {
+                const int start = __builtin_amdgcn_readfirstlane(start_row);
+                const int dropped = pruned_search(win, ref, need, start, best);
+                // the wave's next chunk starts where its first live block matched
+                const int src = __ffsll((long long)needing) - 1;
+                start_row = (int)((uint32_t)__shfl((int)best, src, 64) & 0xFFFFu) / 9;
+                prune_pays = dropped >= 2;
+            }
+        }
+        if (!need) {
+            if (live) {
+                *out = __builtin_bit_cast(uint32_t, rec);
+                if (SUBPIXEL) a.subdirs[item] = 8;
+            }
+            return 8;
+        }
+    } else {
+        best = exhaustive_search<EQ>(win, ref, delta);
+    }
+    const int idx = (int)(best & 0xFFFFu);
+    rec.dx = (int8_t)(px + idx % 9 - 4);
+    rec.dy = (int8_t)(py + idx / 9 - 4);
+    rec.sad = (uint16_t)(best >> 16);
+    *out = __builtin_bit_cast(uint32_t, rec);
+
+    // Half-pixel refinement of accepted blocks: the ring of the best match, rows -1..8 and
+    // bytes -1..8, again straight from global memory (the lines were touched a moment ago).
+    int subdir = 8;
+    if constexpr (SUBPIXEL) {
+        if ((uint32_t)rec.sad < (uint32_t)a.value_threshold) {
+            const uint32_t ring = off_cur + (uint32_t)((idx / 9 - 1) * W + (idx % 9 - 1));
+            uint32_t rows[10][3];
+#pragma unroll
+            for (int y = 0; y < 10; y++) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_cur, ring, y * W, 0);
+                rows[y][0] = v.x; rows[y][1] = v.y;
+                rows[y][2] = __builtin_amdgcn_raw_buffer_load_b16(rs_cur, ring + 8, y * W, 0);
+            }
+            RefineState<2> st;
+            st.init();
+            for_rows<-1, 8>([&](auto yc) {
+                constexpr int Y = decltype(yc)::value;
+                uint32_t d[3] = {rows[Y + 1][0], rows[Y + 1][1], rows[Y + 1][2]};
+                if (delta != 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) d[q] = sat_add_u8x4(d[q], delta);
+                }
+                st.template row<Y>(d, ref);
+            });
+            subdir = st.direction(rec.sad);
+        }
+        a.subdirs[item] = (uint8_t)subdir;
+    }
+    return subdir;
+}
+
+}  // namespace
+
+}  // namespace aof

@@ -87,8 +87,11 @@ __device__ __forceinline__ void write_flow(const FlowTail &a, int64_t pair, int 
 // lane k holds bin k of both histograms, the first maximum is a wave maximum + ballot, the window
 // sums are wave sums, lane 0 does the divisions.  One lane alone walks the bins with dependent LDS
 // reads (2 us for 19 bins) while its workgroup -- in k_coarse the whole CU -- waits.  n <= 64.
+// record_out (optional, LDS): lane 0 also leaves the record there; pred_rec (optional): the level-1
+// record to copy the predictor fields from, instead of a.pred[pair] in global memory.
 __device__ __forceinline__ void finalise_flow_wave(const FlowTail &a, int64_t pair, const uint32_t *hist_x,
-                                                   const uint32_t *hist_y, const int *sums)
+                                                   const uint32_t *hist_y, const int *sums, aof_flow *record_out = nullptr,
+                                                   const aof_flow *pred_rec = nullptr)
 {
     const int centre = 2 * a.range + 1, n = 2 * centre + 1;
     const int k = (int)(threadIdx.x & 63);
@@ -147,12 +150,13 @@ __device__ __forceinline__ void finalise_flow_wave(const FlowTail &a, int64_t pa
             out.pred_x = (int8_t)pred;
             out.pred_y = (int8_t)pred_y;
         } else if (a.pred) {
-            const aof_flow p = a.pred[pair];
+            const aof_flow p = pred_rec ? *pred_rec : a.pred[pair];
             out.pred_x = p.pred_x;
             out.pred_y = p.pred_y;
             if (p.flags & AOF_FLAG_FLOW_VALID) out.flags |= AOF_FLAG_PRED_VALID;
         }
         a.flows[pair] = out;
+        if (record_out) *record_out = out;
     }
 }
 

@@ -1,0 +1,344 @@
+// KS -- a whole small pair, one or two levels, in ONE workgroup, ONE launch and out of LDS
+// (DESIGN.md "Kernels": KS).
+//
+// The call shape of the reference -- one small frame per calcFlow(), mainloop.cpp:322 -- is bound by
+// launches and memory round trips, not by arithmetic.  As separate kernels two levels are a memset,
+// K1, the level-1 search and the level-0 search (four graph nodes, 45 us per call), and each search
+// is a few dozen lanes walking all 81 candidates of their block alone, every row from memory.  Here
+// one workgroup does the lot for a pair whose frames fit LDS and whose grids have at most 256 blocks
+// (the published sparse grid: 25):
+//   A  both level-0 frames: global (or pinned host) memory -> LDS, every load issued before the
+//      first use -- one round trip --, pixel sums on the way;
+//   B  two levels: 2x2 box pyramid LDS -> LDS, level-1 sums;
+//   C  per level: one lane per (block, dy) -- nine lanes share a block, 25 blocks fill the workgroup --
+//      reads tile and window rows from LDS at any byte offset (aligned dwords + v_alignbyte), sums its
+//      nine dx candidates with v_qsad_pk_u16_u8 / v_sad_hi_u8 and joins its block through one LDS
+//      atomicMin on the packed key (sad << 16 | idx): first minimum in scan order;
+//   D  one lane per block: record, half-pixel refinement from LDS, votes; wave 0 finalises the
+//      level's flow record; the level-1 predictor reaches level 0 through LDS.
+// Nothing but the block records, the flow records and the sums leaves the chip (the level-1 frames of
+// the workspace stay untouched, as under the fused coarse kernel).  Results are those of the separate
+// kernels bit for bit.
+#include "aof_device.hpp"
+#include "aof_internal.hpp"
+#include "aof_reduce.hpp"
+#include "aof_refine.hpp"
+
+namespace aof {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBins = 64;   // n = 2(2R+1)+1: 19 at level 1 (and for one level), 55 at level 0 of two (S = 4)
+constexpr int kLoads = 8;      // 16-byte chunks a thread has in flight in pass A
+constexpr int kPad = 16;       // bytes after each LDS frame: the dword reads of the last row may run past it
+
+__device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | lo; }
+
+// Unaligned reads from an LDS frame: aligned dwords, funnel-shifted by the byte offset's low bits.
+__device__ __forceinline__ uint4 lds_bytes16(const uint8_t *frame, int off)
+{
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(frame) + (off >> 2);
+    const uint32_t sh = (uint32_t)off & 3u;
+    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+    return make_uint4(__builtin_amdgcn_alignbyte(q1, q0, sh), __builtin_amdgcn_alignbyte(q2, q1, sh),
+                      __builtin_amdgcn_alignbyte(q3, q2, sh), __builtin_amdgcn_alignbyte(q4, q3, sh));
+}
+__device__ __forceinline__ void lds_bytes8(const uint8_t *frame, int off, uint32_t (&out)[2])
+{
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(frame) + (off >> 2);
+    const uint32_t sh = (uint32_t)off & 3u;
+    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
+    out[0] = __builtin_amdgcn_alignbyte(q1, q0, sh);
+    out[1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
+}
+__device__ __forceinline__ void lds_bytes12(const uint8_t *frame, int off, uint32_t (&out)[3])
+{
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(frame) + (off >> 2);
+    const uint32_t sh = (uint32_t)off & 3u;
+    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    out[0] = __builtin_amdgcn_alignbyte(q1, q0, sh);
+    out[1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
+    out[2] = __builtin_amdgcn_alignbyte(q3, q2, sh);
+}
+
+// 4x4 gradient gate on tile bytes [2..5] x rows [2..5] (same arithmetic as aof_lane8.hpp)
+__device__ __forceinline__ uint32_t gate_4x4(const uint32_t (&ref)[8][2])
+{
+    uint32_t mid[4], diff = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) mid[r] = __builtin_amdgcn_alignbyte(ref[r + 2][1], ref[r + 2][0], 2);
+#pragma unroll
+    for (int r = 0; r < 3; r++) diff = __builtin_amdgcn_sad_u8(mid[r], mid[r + 1], diff);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        diff = __builtin_amdgcn_sad_u8(mid[r], __builtin_amdgcn_perm(0u, mid[r], 0x03030201u), diff);
+    return diff;
+}
+
+struct LevelMeta { int px, py, delta; };
+
+// One level of one pair out of LDS: search, records, refinement, votes, flow record.
+// `keys`: one packed key per block; `record_out`: LDS copy of the flow record (level 1: it carries the
+// predictor); `pred_rec`: the level-1 record whose predictor fields level 0 copies into its own.
+template <bool SUBPIXEL>
+__device__ __forceinline__ void run_level(const SearchArgs &a, const FlowTail &tail, uint32_t pair, const uint8_t *fp,
+                                          const uint8_t *fc, const LevelMeta &m, uint32_t *keys,
+                                          uint32_t (*votes)[kMaxBins], int *tot, aof_flow *record_out,
+                                          const aof_flow *pred_rec)
+{
+    const int tid = threadIdx.x, W = a.w;
+    const int nb = a.grid.blocks(), nx = a.grid.nx;
+    const int centre = 2 * tail.range + 1;
+    constexpr int ring = SUBPIXEL ? 1 : 0;
+    for (int k = tid; k < nb; k += kThreads) keys[k] = 0xFFFFFFFFu;
+    if (tid < kMaxBins) { votes[0][tid] = 0; votes[1][tid] = 0; }
+    if (tid < 3) tot[tid] = 0;
+    __syncthreads();
+
+    // ---- C: one lane per (block, dy) ----
+    for (int it = tid; it < nb * 9; it += kThreads) {
+        const int blk = it / 9, d = it - blk * 9;
+        const int by = blk / nx, bx = blk - by * nx;
+        const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y;
+        const int wx0 = i + m.px - 4, wy0 = j + m.py - 4;
+        // the search window (plus the half-pixel ring) must lie inside the frame
+        if (wx0 - ring < 0 || wy0 - ring < 0 || wx0 + 16 + ring > a.w || wy0 + 16 + ring > a.h) continue;
+        uint32_t ref[8][2];
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds_bytes8(fp, (j + r) * W + i, ref[r]);
+        if (gate_4x4(ref) < (uint32_t)a.feature_threshold) continue;
+        u64 lo = 0, hi = 0;
+        uint32_t k8 = (uint32_t)(d * 9 + 8);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint4 w = lds_bytes16(fc, (wy0 + d + r) * W + wx0);
+            if (m.delta != 0) w = sat_add_u8x16(w, m.delta);
+            const u64 p01 = pack64(w.x, w.y), p12 = pack64(w.y, w.z), p23 = pack64(w.z, w.w);
+            lo = __builtin_amdgcn_qsad_pk_u16_u8(p01, ref[r][0], lo);
+            lo = __builtin_amdgcn_qsad_pk_u16_u8(p12, ref[r][1], lo);
+            hi = __builtin_amdgcn_qsad_pk_u16_u8(p12, ref[r][0], hi);
+            hi = __builtin_amdgcn_qsad_pk_u16_u8(p23, ref[r][1], hi);
+            k8 = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], k8);
+            k8 = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], k8);
+        }
+        const uint32_t base = (uint32_t)(d * 9);
+        const uint32_t l0 = (uint32_t)lo, l1 = (uint32_t)(lo >> 32), h0 = (uint32_t)hi, h1 = (uint32_t)(hi >> 32);
+        uint32_t best = min(min((l0 << 16) | (base + 0), (l0 & 0xFFFF0000u) | (base + 1)),
+                            min((l1 << 16) | (base + 2), (l1 & 0xFFFF0000u) | (base + 3)));
+        best = min(best, min(min((h0 << 16) | (base + 4), (h0 & 0xFFFF0000u) | (base + 5)),
+                             min((h1 << 16) | (base + 6), (h1 & 0xFFFF0000u) | (base + 7))));
+        best = min(best, k8);
+        atomicMin(&keys[blk], best);
+    }
+    __syncthreads();
+
+    // ---- D: one lane per block ----
+    const bool live = tid < nb;   // nb <= kThreads
+    aof_block rec;
+    rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
+    int subdir = 8;
+    if (live) {
+        const uint32_t key = keys[tid];
+        const size_t item = (size_t)pair * (size_t)nb + (size_t)tid;
+        if (key != 0xFFFFFFFFu) {
+            const int idx = (int)(key & 0xFFFFu);
+            rec.dx = (int8_t)(m.px + idx % 9 - 4);
+            rec.dy = (int8_t)(m.py + idx / 9 - 4);
+            rec.sad = (uint16_t)(key >> 16);
+            if constexpr (SUBPIXEL) {
+                if ((uint32_t)rec.sad < (uint32_t)a.value_threshold) {
+                    const int by = tid / nx, bx = tid - by * nx;
+                    const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y;
+                    const int rx = i + m.px - 4 + idx % 9 - 1, ry = j + m.py - 4 + idx / 9 - 1;
+                    uint32_t ref[8][2];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) lds_bytes8(fp, (j + r) * W + i, ref[r]);
+                    RefineState<2> st;
+                    st.init();
+                    for_rows<-1, 8>([&](auto yc) {
+                        constexpr int Y = decltype(yc)::value;
+                        uint32_t dd[3];
+                        lds_bytes12(fc, (ry + Y + 1) * W + rx, dd);
+                        if (m.delta != 0) {
+#pragma unroll
+                            for (int q = 0; q < 3; q++) dd[q] = sat_add_u8x4(dd[q], m.delta);
+                        }
+                        st.template row<Y>(dd, ref);
+                    });
+                    subdir = st.direction(rec.sad);
+                }
+            }
+        }
+        reinterpret_cast<uint32_t *>(a.blocks)[item] = __builtin_bit_cast(uint32_t, rec);
+        if (SUBPIXEL) a.subdirs[item] = (uint8_t)subdir;
+    }
+    const bool ok = live && (uint32_t)rec.sad < (uint32_t)a.value_threshold;  // skipped = 0xFFFF
+    const int hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
+    const int hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
+    const int vx = 2 * rec.dx + hx, vy = 2 * rec.dy + hy;
+    wave_vote2(votes[0], votes[1], vx + centre, vy + centre, ok);
+    const int s2x = (int)wave_sum_u32((uint32_t)(ok ? vx : 0)), s2y = (int)wave_sum_u32((uint32_t)(ok ? vy : 0));
+    const int cnt = (int)wave_sum_u32(ok ? 1u : 0u);
+    if ((tid & 63) == 0 && cnt) {
+        atomicAdd(&tot[0], s2x);
+        atomicAdd(&tot[1], s2y);
+        atomicAdd(&tot[2], cnt);
+    }
+    __syncthreads();
+    if (tid < 64) finalise_flow_wave(tail, pair, votes[0], votes[1], tot, record_out, pred_rec);   // bins <= 64 (launcher)
+}
+
+template <bool SUBPIXEL>
+__global__ __launch_bounds__(kThreads) void k_flow_small(SmallArgs a)   // (latency path: occupancy does not matter)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    __shared__ uint32_t s_keys[kThreads];
+    __shared__ uint32_t s_votes[2][kMaxBins];
+    __shared__ int s_tot[3];
+    __shared__ aof_flow s_flow1;     // the level-1 flow record: predictor of level 0
+    __shared__ uint32_t s_sums[4];   // [frame][level]
+    const uint32_t pair = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int w = a.l0.w, h = a.l0.h, w1 = w / 2, h1 = h / 2;
+    const int frame0 = w * h, frame1 = w1 * h1;
+    const bool two = a.levels == 2;
+    uint8_t *f0[2] = {s_mem, s_mem + frame0 + kPad};
+    uint8_t *f1[2] = {s_mem + 2 * (frame0 + kPad), s_mem + 2 * (frame0 + kPad) + ((frame1 + kPad + 15) & ~15)};
+
+    if (tid < 4) s_sums[tid] = 0;
+    __syncthreads();
+
+    // ---- A: level-0 frames -> LDS (a frame is contiguous: row stride == w) ----
+    {
+        const int per_frame = frame0 / 16, items = 2 * per_frame;
+        uint32_t sum[2] = {0, 0};
+        for (int base = 0; base < items; base += kLoads * kThreads) {
+            uint4 v[kLoads];
+#pragma unroll
+            for (int k = 0; k < kLoads; k++) {
+                const int it = base + k * kThreads + tid;
+                v[k] = make_uint4(0, 0, 0, 0);
+                if (it < items) {
+                    const int frame = it >= per_frame, c = it - frame * per_frame;
+                    const uint8_t *src = (frame ? a.l0.cur : a.l0.prev) + (int64_t)pair * a.l0.pair_stride;
+                    v[k] = *reinterpret_cast<const uint4 *>(src + c * 16);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kLoads; k++) {
+                const int it = base + k * kThreads + tid;
+                if (it >= items) continue;
+                const int frame = it >= per_frame, c = it - frame * per_frame;
+                uint32_t s = 0;
+                s = byte_sum(v[k].x, s); s = byte_sum(v[k].y, s);
+                s = byte_sum(v[k].z, s); s = byte_sum(v[k].w, s);
+                sum[frame] += s;
+                *reinterpret_cast<uint4 *>(f0[frame] + c * 16) = v[k];
+            }
+        }
+        if (a.sums) {
+#pragma unroll
+            for (int frame = 0; frame < 2; frame++) {
+                const uint32_t t = wave_sum_u32(sum[frame]);
+                if ((tid & 63) == 0) atomicAdd(&s_sums[frame * 2], t);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- B: level-1 frames, LDS -> LDS ----
+    if (two) {
+        const int chunks = w / 16, per_frame = h1 * chunks;
+        uint32_t sum[2] = {0, 0};
+        for (int it = tid; it < 2 * per_frame; it += kThreads) {
+            const int frame = it >= per_frame, rest = it - frame * per_frame;
+            const int y1 = rest / chunks, c = rest - y1 * chunks;
+            const uint4 r0 = *reinterpret_cast<const uint4 *>(f0[frame] + (2 * y1) * w + c * 16);
+            const uint4 r1 = *reinterpret_cast<const uint4 *>(f0[frame] + (2 * y1 + 1) * w + c * 16);
+            const uint32_t p0 = box2(r0.x, r1.x), p1 = box2(r0.y, r1.y);
+            const uint32_t p2 = box2(r0.z, r1.z), p3 = box2(r0.w, r1.w);
+            uint2 o;
+            o.x = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
+            o.y = __builtin_amdgcn_perm(p3, p2, 0x06040200u);
+            sum[frame] = byte_sum(o.x, sum[frame]);
+            sum[frame] = byte_sum(o.y, sum[frame]);
+            *reinterpret_cast<uint2 *>(f1[frame] + y1 * w1 + c * 8) = o;
+        }
+        if (a.sums) {
+#pragma unroll
+            for (int frame = 0; frame < 2; frame++) {
+                const uint32_t t = wave_sum_u32(sum[frame]);
+                if ((tid & 63) == 0) atomicAdd(&s_sums[frame * 2 + 1], t);
+            }
+        }
+        __syncthreads();
+    }
+
+    LevelMeta m0 = {0, 0, 0}, m1 = {0, 0, 0};
+    if (a.sums) {
+        const uint32_t n0 = (uint32_t)frame0;
+        m0.delta = (int)((s_sums[0] + n0 / 2) / n0) - (int)((s_sums[2] + n0 / 2) / n0);
+        if (two) {
+            const uint32_t n1 = (uint32_t)frame1;
+            m1.delta = (int)((s_sums[1] + n1 / 2) / n1) - (int)((s_sums[3] + n1 / 2) / n1);
+        }
+        if (tid < 4) a.sums[(size_t)pair * 4 + tid] = s_sums[tid];
+    }
+
+    if (two) {
+        run_level<SUBPIXEL>(a.l1, a.t1, pair, f1[0], f1[1], m1, s_keys, s_votes, s_tot, &s_flow1, nullptr);
+        __syncthreads();
+        m0.px = s_flow1.pred_x;
+        m0.py = s_flow1.pred_y;
+    }
+    run_level<SUBPIXEL>(a.l0, a.t0, pair, f0[0], f0[1], m0, s_keys, s_votes, s_tot, nullptr, two ? &s_flow1 : nullptr);
+}
+
+size_t small_lds_bytes(const SmallArgs &a)
+{
+    const size_t frame0 = (size_t)a.l0.w * a.l0.h, frame1 = (size_t)(a.l0.w / 2) * (a.l0.h / 2);
+    size_t bytes = 2 * (frame0 + kPad);
+    if (a.levels == 2) bytes += 2 * ((frame1 + kPad + 15) & ~(size_t)15);
+    return bytes;
+}
+
+}  // namespace
+
+bool flow_small_supported(const SmallArgs &a)
+{
+    const SearchArgs &l0 = a.l0, &l1 = a.l1;
+    if (a.levels != 1 && a.levels != 2) return false;
+    if (l0.tile != 8 || l0.search != 4) return false;
+    if (l0.n_pairs < 1 || l0.n_pairs > 0x7FFFFFFF / kThreads) return false;
+    if (l0.grid.blocks() < 1 || l0.grid.blocks() > kThreads) return false;
+    if (2 * (2 * a.t0.range + 1) + 1 > kMaxBins) return false;
+    // 16-byte chunks of a contiguous frame
+    if (l0.w % 16 || (l0.n_pairs > 1 && l0.pair_stride % 16)) return false;
+    if (reinterpret_cast<uintptr_t>(l0.prev) % 16 || reinterpret_cast<uintptr_t>(l0.cur) % 16) return false;
+    if (l0.subpixel && !l0.subdirs) return false;
+    if (a.levels == 2) {
+        if (l0.h % 2 || l1.w != l0.w / 2 || l1.h != l0.h / 2) return false;
+        if (l1.grid.blocks() < 1 || l1.grid.blocks() > kThreads) return false;
+        if (2 * (2 * a.t1.range + 1) + 1 > kMaxBins) return false;
+        if (l0.subpixel && !l1.subdirs) return false;
+    }
+    return small_lds_bytes(a) + 4096 <= 160 * 1024;   // frames + the kernel's static arrays
+}
+
+int launch_flow_small(const SmallArgs &a, void *stream)
+{
+    if (a.l0.n_pairs == 0) return 0;
+    if (!flow_small_supported(a)) return (int)hipErrorInvalidValue;
+    void (*fn)(SmallArgs) = a.l0.subpixel ? k_flow_small<true> : k_flow_small<false>;
+    const size_t lds = small_lds_bytes(a);
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(fn, dim3((uint32_t)a.l0.n_pairs), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace aof

@@ -16,14 +16,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kItemsPerBlock = 1024;  // 16-px x 2-row items per workgroup
 
-// Two level-1 pixels from one dword of each row, returned in bytes 0 and 2.
-__device__ __forceinline__ uint32_t box2(uint32_t a, uint32_t b)
-{
-    const uint32_t m = 0x00FF00FFu;
-    const uint32_t s = (a & m) + ((a >> 8) & m) + (b & m) + ((b >> 8) & m) + 0x00020002u;
-    return (s >> 2) & m;
-}
-
 __global__ __launch_bounds__(kThreads) void k_pyramid_vec(PyramidArgs a, int rows_per_strip,
                                                           int nstrips)
 {

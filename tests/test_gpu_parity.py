@@ -145,6 +145,63 @@ def test_c3_vga_two_level_mean_subtracted(aof, orc, synth, gpu_device, path):
         assert b1[i].tobytes() == ref["blocks_l1"].tobytes()
 
 
+@pytest.mark.parametrize("kw,w,h", [
+    (dict(px4=1, pyramid_levels=2, mean_subtract=1), 128, 128),   # what OpticalFlowOpenCV runs per call
+    (dict(px4=1, pyramid_levels=2, mean_subtract=1), 64, 64),
+    (dict(px4=1, pyramid_levels=2), 96, 80),
+    (dict(px4=1, pyramid_levels=2, mean_subtract=1, hist_filter=0), 112, 66),   # odd level-1 height
+    (dict(px4=1, pyramid_levels=2, mean_subtract=1, subpixel=0), 128, 96),
+    (dict(pyramid_levels=2, mean_subtract=1), 128, 96),           # dense grid, 15x11 = 165 blocks at level 0
+    (dict(pyramid_levels=2, mean_subtract=1, subpixel=1), 144, 112),            # dense, 16x12 = 192 blocks
+    (dict(pyramid_levels=2, mean_subtract=1, subpixel=1), 256, 224),            # 140 KB of LDS; level 0 falls back? no: 31x27 blocks
+    (dict(px4=1), 64, 64),                                        # one level: what OpticalFlowPX4 runs per call (configs[0])
+    (dict(px4=1, mean_subtract=1), 128, 128),
+    (dict(px4=1, subpixel=0, hist_filter=0), 80, 49),             # odd height
+    (dict(subpixel=1), 96, 96),                                   # dense, 11x11
+])
+@pytest.mark.parametrize("n", [1, 7, 128])
+def test_small_pairs_in_one_launch(aof, orc, synth, gpu_device, kw, w, h, n):
+    """Small pairs (frames fit LDS, grids <= 256 blocks, <= 128 pairs) run sums, pyramid, searches and
+    reductions in ONE kernel out of LDS (k_flow_small).  Outputs against the oracle; block records,
+    flows and the workspace (sums, level-1 records, directions and flows) against the separate
+    kernels, byte for byte."""
+    kw = dict(kw)
+    mk = aof.px4flow_params if kw.pop("px4", 0) else aof.default_params
+    p = mk(w, h, **kw)
+    two = p.pyramid_levels == 2
+    prevs, curs, shifts = synth.make_batch(w, h, n, 9 if two else 4, 7000 + n, noise=3, brightness=9)
+    one = run_gpu(aof, p, prevs, curs, gpu_device, want_ws=True)
+    sep = run_gpu(aof, p, prevs, curs, gpu_device, want_ws=True, split_coarse=True)
+    g0 = aof.grid(p, 0)
+    fits = g0[4] * g0[5] <= 256
+    if n == 7:   # one launch: no pyramid kernel, no level-1 kernels, no reduction kernel
+        import torch
+        eng = aof.FlowEngine(p, 0)
+        eng.set_profiling(True)
+        eng.flow_batch(torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device))
+        torch.cuda.synchronize()
+        launches = [len(eng.profile_ms(k)) for k in range(5)]
+        assert (launches == [0, 0, 0, 1, 0]) == fits, launches
+    assert one["blocks"].tobytes() == sep["blocks"].tobytes()
+    assert one["flows"].tobytes() == sep["flows"].tobytes()
+    L = aof.workspace_layout(p, n)
+    regions = []
+    if two:
+        g1 = aof.grid(p, 1)
+        nb1 = g1[4] * g1[5]
+        regions += [(L.l1_blocks, n * nb1 * 4), (L.l1_flows, n * 16)]
+        if p.subpixel:
+            regions.append((L.l1_subdirs, n * nb1))
+    if p.mean_subtract:   # [pair][frame][level]; one level: only the level-0 sums mean anything
+        a, b = (x["ws"][L.sums:L.sums + n * 16].view(np.uint32).reshape(n, 2, 2) for x in (one, sep))
+        assert np.array_equal(a, b) if two else np.array_equal(a[:, :, 0], b[:, :, 0])
+    for off, size in regions:
+        assert one["ws"][off:off + size].tobytes() == sep["ws"][off:off + size].tobytes(), (off, size)
+    sample = sorted(set([0, n // 2, n - 1]))
+    check_against_oracle(aof, orc, p, prevs[sample], curs[sample],
+                         dict(blocks=one["blocks"][sample], flows=one["flows"][sample]))
+
+
 def test_c5_1280x960_16x16_search8(aof, orc, synth, gpu_device):
     """configs[4]: 1280x960, 16x16 SAD +-8 (LDS-tile stress)."""
     p = aof.default_params(1280, 960, tile=16, search=8, value_threshold=12000)

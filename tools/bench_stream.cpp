@@ -9,6 +9,7 @@ int main(int argc, char **argv)
 {
     const int w = argc > 1 ? atoi(argv[1]) : 64, h = argc > 2 ? atoi(argv[2]) : 64, calls = 5000;
     const int levels = argc > 3 ? atoi(argv[3]) : 1;   // 2: what OpticalFlowOpenCV ships (two levels + mean equalisation)
+    const int only = argc > 4 ? atoi(argv[4]) : -1;    // run one mode only (1 = lane8 without the graph: rocprofv3 cannot trace graph launches)
     aof_params p;
     aof_params_px4flow(&p, w, h, 4, 30, 3000);
     if (levels == 2) { p.pyramid_levels = 2; p.mean_subtract = 1; }
@@ -27,6 +28,7 @@ int main(int argc, char **argv)
             }
     }
     for (int mode = 0; mode < 4; mode++) {
+        if (only >= 0 && mode != only) continue;
         const int graph = !(mode & 1), generic = mode >> 1;
         aof_ctx *ctx;
         if (aof_create(&p, 0, &ctx)) { printf("no device\n"); return 1; }

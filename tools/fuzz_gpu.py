@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long differential fuzz on a GPU box (not part of the test suite): random geometry, options
-and image statistics; default, strip-kernel, pruned, generic and split-coarse device paths against the CPU oracle.
+and image statistics; default, strip-kernel, pruned, generic and separate-kernel device paths against the CPU oracle.
     python tools/fuzz_gpu.py [n_cases] [first_seed]"""
 import importlib
 import os
@@ -19,7 +19,41 @@ aof = ge.load_package()
 synth = importlib.import_module("aero_optical_flow_amd.synth")
 
 
+def small_case(rng):
+    """Frames that fit LDS with grids of at most 256 blocks: the one-workgroup kernel (k_flow_small)."""
+    levels = int(rng.choice([1, 2, 2]))
+    grid_mode = int(rng.choice([0, 1, 1]))
+    min_dim = (8 + 2 * 5 + 8) * (2 if levels == 2 else 1)
+    if grid_mode:
+        w = 16 * int(rng.integers((min_dim + 15) // 16, 17))
+        h = int(rng.integers(min_dim, 225))
+    else:   # dense: keep the grid at or below 256 blocks (sometimes just above: the separate kernels)
+        w = 16 * int(rng.integers((min_dim + 15) // 16, 11))
+        h = int(rng.integers(min_dim, 150))
+    if levels == 2:
+        h += h & 1
+    return dict(width=w, height=h, tile=8, search=4, pyramid_levels=levels, grid_mode=grid_mode,
+                subpixel=int(rng.integers(0, 2)), mean_subtract=int(rng.integers(0, 2)), hist_filter=int(rng.integers(0, 2)),
+                feature_threshold=int(rng.choice([0, 30, 30, 200, 2000])),
+                value_threshold=int(rng.choice([0, 500, 3000, 3000, 70000])),
+                min_valid=int(rng.choice([0, 10, 10, 500])), num_blocks=int(rng.integers(2, 9)))
+
+
+def small_eligible(p, g0, g1):
+    """Mirrors flow_small_supported (statistics only)."""
+    if p.tile != 8 or p.search != 4 or p.width % 16 or not 8 <= g0[4] * g0[5] <= 256:
+        return False
+    lds = 2 * (p.width * p.height + 16)
+    if p.pyramid_levels == 2:
+        if p.height % 2 or not 8 <= g1[4] * g1[5] <= 256:
+            return False
+        lds += 2 * ((p.width // 2) * (p.height // 2) + 32)
+    return lds + 4096 <= 160 * 1024
+
+
 def case(rng):
+    if rng.random() < 0.3:
+        return small_case(rng)
     fast = rng.random() < 0.7          # geometries the LDS-tiled kernels serve
     fast16 = fast and rng.random() < 0.2
     tile = (16 if fast16 else 8) if fast or rng.random() < 0.5 else 16
@@ -76,11 +110,12 @@ def main():
             prevs[0] = (((xx // period + yy // period) % 2) * int(rng.integers(1, 256))).astype(np.uint8)
             curs[0] = prevs[0] if rng.random() < 0.5 else 255 - prevs[0]
         po = orc.params_from(p)
+        small = small_eligible(p, aof.grid(p, 0), aof.grid(p, 1) if p.pyramid_levels == 2 else None)
         refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
         tp, tc = torch.from_numpy(prevs).to(dev), torch.from_numpy(curs).to(dev)
         for mode in ("exhaustive", "strips", "pruned", "pruned_strips", "generic", "split"):
-            if mode == "split" and p.pyramid_levels != 2:
-                continue   # (two levels: the coarse passes as separate kernels instead of k_coarse)
+            if mode == "split" and p.pyramid_levels != 2 and not small:
+                continue   # (the separate kernels instead of k_coarse / k_flow_small)
             eng = aof.FlowEngine(p, 0)
             if mode == "split":
                 eng.set_split_coarse(True)
@@ -104,7 +139,8 @@ def main():
                 if not ok:
                     print(f"MISMATCH seed {s} mode {mode} ({eng.variant}) pair {i} style {style}: {kw}", flush=True)
                     sys.exit(1)
-            variants[eng.variant] = variants.get(eng.variant, 0) + 1
+            name = "small_lds" if small and mode in ("exhaustive", "pruned") else eng.variant
+            variants[name] = variants.get(name, 0) + 1
             eng.close()
         done += 1
         if done % 25 == 0:
