@@ -148,7 +148,11 @@ int aof_set_search_mode(aof_ctx *ctx, int mode);
  * d_blocks: [n_pairs][nb0] records (4-byte aligned) or NULL.  d_subdirs: [n_pairs][nb0] or NULL.
  * d_flows: [n_pairs], required.  d_workspace: >= aof_workspace_layout().total_bytes,
  * 256-byte aligned.  stream: hipStream_t (NULL = default stream).
- * Asynchronous: returns after enqueueing; no allocation, no host sync. */
+ * Asynchronous: returns after enqueueing; no allocation, no host sync.
+ * Calls of at most 128 small pairs (8x8 tiles, every grid 8..256 blocks, width a multiple of 16,
+ * frames that fit LDS: the published sparse grid up to about 256x224) run as ONE kernel, a
+ * workgroup per pair, whatever the number of levels; the workspace's level-1 frames then stay
+ * untouched (aof_set_split_coarse(ctx, 1) selects the separate kernels instead). */
 int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_cur,
                           int64_t pair_stride, int64_t n_pairs, aof_block *d_blocks,
                           uint8_t *d_subdirs, aof_flow *d_flows, void *d_workspace,
@@ -158,7 +162,8 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
  * run their coarse passes -- pixel sums, 2x2 pyramid, level-1 search, level-1 reduction -- as
  * ONE kernel, a workgroup per pair, and never write the level-1 frames to memory (the
  * workspace regions l1_prev / l1_cur then stay untouched).  on = 1 runs them as the separate
- * kernels K1 / K2 / K3 instead, which also fills l1_prev / l1_cur (tests compare the two). */
+ * kernels K1 / K2 / K3 instead, which also fills l1_prev / l1_cur (tests compare the two), and
+ * keeps small batches (see aof_flow_batch_device) on the separate kernels as well. */
 int aof_set_split_coarse(aof_ctx *ctx, int on);
 
 /* Two-level configurations cut a large batch into sub-batches and run the HBM-bound coarse

@@ -145,7 +145,7 @@ def main():
         done += 1
         if done % 25 == 0:
             print(f"{done} cases ok ({time.time() - t0:.0f} s), skipped {skipped}, kernels {variants}", flush=True)
-    print(f"fuzz passed: {done} cases x 5 device paths (+ split coarse passes on two-level cases), {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
+    print(f"fuzz passed: {done} cases x 5 device paths (+ the separate kernels on two-level and small-pair cases), {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
