@@ -143,7 +143,8 @@ SearchKind search_kind(const aof_ctx *ctx, const SearchArgs &a)
     // 8x8 tiles runs lane-per-block straight from L2 (measured faster on every dense
     // configuration: full lane use, no staging phases, no barriers).
     const bool strips = ctx->search_mode == AOF_SEARCH_EXHAUSTIVE_STRIPS || ctx->search_mode == AOF_SEARCH_PRUNED_STRIPS;
-    if (strips && tile8_supported(a)) return SK_TILE8;
+    // (tile8_geometry: the workspace layout reserved the strips' vote histograms for this level)
+    if (strips && tile8_supported(a) && tile8_geometry(ctx->params, a.level)) return SK_TILE8;
     if (tile16_supported(a)) return SK_TILE16;
     if (lane8_supported(a)) return lane8_group(a) > 0 ? SK_LANE8_GROUP : SK_LANE8;
     return SK_GENERIC;

@@ -90,11 +90,16 @@ Tile8Plan plan_tile8(int w, int nx, int ny)
 
 bool tile8_geometry(const aof_params &p, int level)
 {
-    if (p.tile != 8 || p.search != 4 || p.grid_mode != AOF_GRID_DENSE) return false;
+    if (p.tile != 8 || p.search != 4) return false;
     const int w = p.width >> level;
     if (w % 16) return false;
     Grid g;
     if (grid_for_level(p, level, &g)) return false;
+    // The same shape test as tile8_supported (k_search_tile8.hip), NOT the grid mode: a published
+    // sparse grid whose step comes out as 8 from origin 4 (+1) is such a grid too, the strip kernel
+    // takes it, and its per-strip histograms need their workspace.
+    const int org = p.subpixel ? 1 : 0;
+    if (g.x0 != 4 + org || g.y0 != 4 + org || g.step_x != 8 || g.step_y != 8) return false;
     return plan_tile8(w, g.nx, g.ny).rb > 0;
 }
 

@@ -202,6 +202,41 @@ def test_small_pairs_in_one_launch(aof, orc, synth, gpu_device, kw, w, h, n):
                          dict(blocks=one["blocks"][sample], flows=one["flows"][sample]))
 
 
+@pytest.mark.parametrize("levels", [1, 2])
+def test_every_mode_stays_inside_the_workspace(aof, orc, synth, gpu_device, levels):
+    """A published sparse grid whose step comes out as 8 from origin 5 has the shape of a dense grid:
+    the strip kernel takes it in the ..._STRIPS modes and votes into per-strip histograms, which the
+    workspace layout must have reserved (it once sized them by grid mode and the kernel wrote 880
+    bytes past the end).  Guard bytes behind the workspace, every search mode and kernel choice."""
+    import torch
+    p = aof.px4flow_params(64, 64, num_blocks=6, pyramid_levels=levels, min_valid=0)
+    assert aof.grid(p, 0)[:4] == (5, 5, 8, 8)
+    n = 2
+    prevs, curs, _ = synth.make_batch(64, 64, n, 4, 4242, noise=2)
+    tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
+    L = aof.workspace_layout(p, n)
+    assert L.total_bytes > L.l0_hist, "the strips' histograms need room in the layout"
+    po = orc.params_from(p)
+    refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
+    for mode in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_EXHAUSTIVE_STRIPS, aof.SEARCH_PRUNED, aof.SEARCH_PRUNED_STRIPS,
+                 "generic", "split"):
+        eng = aof.FlowEngine(p, 0)
+        if mode == "generic":
+            eng.force_generic(True)
+        elif mode == "split":
+            eng.set_split_coarse(True)
+        else:
+            eng.set_search_mode(mode)
+        big = torch.full((L.total_bytes + 8192,), 0xAB, dtype=torch.uint8, device=gpu_device)
+        blocks, flows, _ = eng.flow_batch(tp, tc, workspace=big[:L.total_bytes])
+        torch.cuda.synchronize()
+        assert bool((big[L.total_bytes:] == 0xAB).all()), f"mode {mode} wrote behind the workspace"
+        assert np.array_equal(tc.cpu().numpy(), curs) and np.array_equal(tp.cpu().numpy(), prevs)
+        gb, gf = aof.blocks_view(blocks), aof.flows_view(flows)
+        for i in range(n):
+            assert gb[i].tobytes() == refs[i]["blocks"].tobytes() and gf[i].tobytes() == refs[i]["flow"].tobytes(), (mode, i)
+
+
 def test_c5_1280x960_16x16_search8(aof, orc, synth, gpu_device):
     """configs[4]: 1280x960, 16x16 SAD +-8 (LDS-tile stress)."""
     p = aof.default_params(1280, 960, tile=16, search=8, value_threshold=12000)

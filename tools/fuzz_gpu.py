@@ -128,16 +128,64 @@ def main():
             elif mode == "pruned_strips":
                 eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
             nb = eng.nblocks(0)
-            sub = torch.full((n, nb), 99, dtype=torch.uint8, device=dev) if p.subpixel else None
-            blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+            # every output carved out of one arena with guard zones in between: a kernel that writes
+            # outside its buffers is caught even when the records it returns are right
+            L = aof.workspace_layout(p, n)
+            G = 1024
+            sizes = [L.total_bytes, n * nb * 4, n * 16, n * nb]
+            offs, off = [], G
+            for sz in sizes:
+                offs.append(off)
+                off = (off + sz + G + 255) // 256 * 256
+            arena = torch.full((off,), 0xAB, dtype=torch.uint8, device=dev)
+            view = lambda k: arena[offs[k]:offs[k] + sizes[k]]
+            sub = view(3).view(n, nb) if p.subpixel else None
+            if sub is not None:
+                sub.fill_(99)
+            blocks, flows, _ = eng.flow_batch(tp, tc, blocks=view(1).view(torch.int32).view(n, nb), flows=view(2).view(n, 16),
+                                              subdirs=sub, workspace=view(0))
             torch.cuda.synchronize()
+            mask = torch.ones(off, dtype=torch.bool, device=dev)
+            for k in range(4):
+                mask[offs[k]:offs[k] + sizes[k]] = False
+            if not p.subpixel:
+                mask[offs[3]:offs[3] + sizes[3]] = True
+            if not bool((arena[mask] == 0xAB).all()):
+                hit = torch.nonzero(mask & (arena != 0xAB)).reshape(-1).cpu().numpy()
+                print(f"GUARD HIT seed {s} mode {mode} ({eng.variant}): {hit.size} bytes outside the buffers, arena offsets "
+                      f"{hit[:6]} .. {hit[-3:]}; buffers at {offs} sizes {sizes}: {kw}", flush=True)
+                sys.exit(1)
             gb, gf = aof.blocks_view(blocks), aof.flows_view(flows)
+            if True:   # ... or the frames
+                for name, t, ref in (("prev", tp, prevs), ("cur", tc, curs)):
+                    got = t.cpu().numpy()
+                    if not np.array_equal(got, ref):
+                        dd = np.nonzero(got.reshape(-1) != ref.reshape(-1))[0]
+                        print(f"FRAME CORRUPTED seed {s} after mode {mode}: {name} differs at {dd.size} bytes, offsets "
+                              f"{dd[:8]} .. {dd[-3:]}, device bytes {got.reshape(-1)[dd[:24]]}: {kw}")
+                        print(f"  pointers: prev {tp.data_ptr():#x} cur {tc.data_ptr():#x} blocks {blocks.data_ptr():#x} "
+                              f"flows {flows.data_ptr():#x} sub {sub.data_ptr() if sub is not None else 0:#x} ", flush=True)
+                        sys.exit(1)
             for i in range(n):
                 ok = gb[i].tobytes() == refs[i]["blocks"].tobytes() and gf[i].tobytes() == refs[i]["flow"].tobytes()
                 if ok and sub is not None:
                     ok = bool(np.array_equal(sub[i].cpu().numpy(), refs[i]["subdirs"]))
                 if not ok:
                     print(f"MISMATCH seed {s} mode {mode} ({eng.variant}) pair {i} style {style}: {kw}", flush=True)
+                    d = np.nonzero(gb[i].view(np.uint32) != refs[i]["blocks"].view(np.uint32))[0]
+                    print(f"  block records differ at {d[:8]}: gpu {gb[i][d[:4]]} oracle {refs[i]['blocks'][d[:4]]}")
+                    print(f"  flow gpu {gf[i]} oracle {refs[i]['flow']}")
+                    if sub is not None:
+                        a = sub[i].cpu().numpy()
+                        d = np.nonzero(a != refs[i]["subdirs"])[0]
+                        print(f"  directions differ at {d[:8]}: gpu {a[d[:8]]} oracle {refs[i]['subdirs'][d[:8]]}")
+                    print(f"  device frames intact: prev {bool(np.array_equal(tp.cpu().numpy(), prevs))} "
+                          f"cur {bool(np.array_equal(tc.cpu().numpy(), curs))}")
+                    dd = np.nonzero(tc.cpu().numpy().reshape(-1) != curs.reshape(-1))[0]
+                    if dd.size:
+                        print(f"  cur differs at {dd.size} bytes, offsets {dd[:6]} .. {dd[-3:]}; device bytes {tc.cpu().numpy().reshape(-1)[dd[:16]]}")
+                    print(f"  pointers: prev {tp.data_ptr():#x} cur {tc.data_ptr():#x} blocks {blocks.data_ptr():#x} "
+                          f"flows {flows.data_ptr():#x}", flush=True)
                     sys.exit(1)
             name = "small_lds" if small and mode in ("exhaustive", "pruned") else eng.variant
             variants[name] = variants.get(name, 0) + 1
