@@ -334,6 +334,9 @@ def main():
                     help="largest synthetic shift per axis (default: the workload's search reach)")
     ap.add_argument("--force-generic", action="store_true", help="time the generic wave-per-block kernel")
     ap.add_argument("--noise", type=int, default=0, help="+-LSB uniform noise added to the current frames")
+    ap.add_argument("--brightness", type=int, default=None,
+                    help="exposure step added to the current frames (default: 9 grey levels for workloads with "
+                         "mean equalisation, so that it has work to do; 0 = SURVEY 8(d)'s pure translations)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --pairs per GPU (default); strong: --pairs in total, sharded over the "
                          "GPUs (BASELINE configs[3]: 1024 pairs over 8 GPUs)")
@@ -410,8 +413,9 @@ def main():
             sys.exit("--scaling strong needs --pairs divisible by the number of GPUs")
     else:
         n = args.pairs
+    brightness = args.brightness if args.brightness is not None else (9 if p.mean_subtract else 0)
     prev, cur, shifts = make_batch_gpu(W, H, n, reach, 0xA0F + 7919 * rank, device,
-                                       brightness=9 if p.mean_subtract else 0)
+                                       brightness=brightness)
     if args.noise:
         g = torch.Generator(device=device)
         g.manual_seed(99 + rank)
@@ -551,7 +555,7 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_gpu": n, "global_pairs": world * n,
-                   "search_kernel": eng.variant, "search": args.search, "coarse": args.coarse, "k2_launches_per_step": lps, "noise_lsb": args.noise, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
+                   "search_kernel": eng.variant, "search": args.search, "coarse": args.coarse, "k2_launches_per_step": lps, "noise_lsb": args.noise, "exposure_step": brightness, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
