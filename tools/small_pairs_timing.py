@@ -1,7 +1,21 @@
-import sys, numpy as np, torch, importlib
-sys.path.insert(0, '.')
-aof = importlib.import_module('aero-optical-flow_amd')
-synth = importlib.import_module('aero-optical-flow_amd.synth')
+#!/usr/bin/env python3
+"""Event-timed kernels of small device-resident pairs (the published sparse grid): the one-workgroup
+kernel k_flow_small against the separate kernels (aof_set_split_coarse), 1 .. 256 pairs per call.
+Each figure includes the ~6 us an event pair costs around any kernel.
+    python tools/small_pairs_timing.py            (also: rocprofv3 --kernel-trace --stats -- python3 tools/...)"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+aof = ge.load_package()
+synth = importlib.import_module(ge.PKG_NAME + ".synth")
 dev = torch.device('cuda:0')
 for w, h in ((64, 64), (128, 128)):
     for levels in (1, 2):
