@@ -154,6 +154,8 @@ def test_c3_vga_two_level_mean_subtracted(aof, orc, synth, gpu_device, path):
     (dict(pyramid_levels=2, mean_subtract=1), 128, 96),           # dense grid, 15x11 = 165 blocks at level 0
     (dict(pyramid_levels=2, mean_subtract=1, subpixel=1), 144, 112),            # dense, 16x12 = 192 blocks
     (dict(pyramid_levels=2, mean_subtract=1, subpixel=1), 256, 224),            # 140 KB of LDS; level 0 falls back? no: 31x27 blocks
+    (dict(px4=1, pyramid_levels=2, mean_subtract=1), 256, 224),   # sparse grid on 143 KB of LDS (dynamic LDS beyond 64 KB)
+    (dict(px4=1), 320, 240),                                      # one level, 154 KB of LDS
     (dict(px4=1), 64, 64),                                        # one level: what OpticalFlowPX4 runs per call (configs[0])
     (dict(px4=1, mean_subtract=1), 128, 128),
     (dict(px4=1, subpixel=0, hist_filter=0), 80, 49),             # odd height
