@@ -64,6 +64,67 @@ def case_plain_average_and_min_valid():
     return prev, cur, blocks, plain, starved
 
 
+def case_exposure_step():
+    """24x24, no motion, cur = prev + 4 grey levels (the texture stays below 251: nothing saturates).
+    mean = floor((sum + N/2)/N): mean(cur) = mean(prev) + 4 exactly, so delta = -4 and the equalised
+    cur' = clamp(cur - 4) = prev: every record (0, 0, 0), where the raw frames would give SAD
+    64*4 = 256 at the same place.  Votes: bins 9 / 9, four each -> flow (0, 0), quality 255."""
+    prev = texture(24, 24)
+    cur = (prev.astype(np.int32) + 4).astype(np.uint8)
+    params = dict(width=24, height=24, min_valid=0, mean_subtract=1)
+    flow = dict(flow_x=0.0, flow_y=0.0, count=4, quality=255, flags=1)
+    return prev, cur, params, [(0, 0, 0)] * 4, flow
+
+
+def case_two_levels_reach_six_pixels():
+    """48x48, two levels, cur[y][x] = prev[y+2][x-6]: a shift of (+6, -2), beyond the +-4 of one level.
+    Level 1 = 2x2 box means; an EVEN shift commutes with the box filter, so cur1[y][x] =
+    prev1[y+1][x-3] and the four level-1 blocks (24x24, origin 4, step 8) match at (3, -1) with SAD 0:
+    level-1 flow (3, -1) in level-1 pixels, predictor = (6, -2) level-0 pixels, valid.
+    Level 0: 5x5 blocks at 4, 12, .., 36.  Under the predictor the window of a block at (i, j) spans
+    x = i+2 .. i+17, y = j-6 .. j+9: inside the 48x48 frame for i <= 30 and j >= 6, i.e. columns
+    4..28 and rows 12..36 -- 16 blocks, each matching at the window's centre: (6, -2, 0); the other nine
+    are skipped (0, 0, 0xFFFF).  Histogram range R = 3S+1 = 13, centre 27: x bin 2*6+27 = 39, y bin
+    -4+27 = 23, 16 votes each, lone peaks -> flow (6.0, -2.0); count 16; quality = floor(16*255/25) =
+    163; flags = flow valid | predictor valid = 3."""
+    prev = texture(48, 48)
+    cur = np.full((48, 48), 3, np.uint8)
+    cur[0:46, 6:48] = prev[2:48, 0:42]
+    params = dict(width=48, height=48, min_valid=0, pyramid_levels=2)
+    blocks = []
+    for j in (4, 12, 20, 28, 36):
+        for i in (4, 12, 20, 28, 36):
+            blocks.append((6, -2, 0) if i <= 30 and j >= 6 else (0, 0, 0xFFFF))
+    flow = dict(flow_x=6.0, flow_y=-2.0, count=16, quality=163, flags=3)
+    return prev, cur, params, blocks, flow
+
+
+def case_half_pixel():
+    """40x40 with half-pixel refinement (dense grid at origin S+1 = 5, step 8: 3x3 blocks).
+    prev[y][x] = (cur[y][x] + cur[y][x+1]) >> 1: prev is cur sampled half a pixel to the right.  Whatever
+    integer match a block finds -- dx = 0 or dx = +1, the texture decides, so the records are not
+    written down here --, the half-pixel image between the two, (a+b)>>1 of horizontally adjacent cur
+    pixels, IS the tile: direction +x from dx = 0 or direction -x from dx = +1 has SAD 0 and wins.
+    Either way the vote is 2*dx +- 1 = +1 half-pixel: bin 1 + 9 = 10 nine times, y bin 9 ->
+    flow = (0.5, 0.0); count 9; quality 255.  (A smooth texture here: on the rough one of the other
+    cases a half-pixel-misaligned tile loses the integer search to some unrelated place.)"""
+    y, x = np.mgrid[0:40, 0:41].astype(np.float64)   # smooth and non-periodic: the true match must win the integer search
+    wide = np.rint(128 + 55 * np.sin(0.37 * x + 0.11 * y) + 45 * np.sin(0.083 * x - 0.29 * y + 0.004 * x * y)
+                   + 20 * np.sin(0.9 * y + 0.05 * x * x / 40)).astype(np.uint8)
+    cur = np.ascontiguousarray(wide[:, :40])
+    prev = ((wide[:, :40].astype(np.int32) + wide[:, 1:41]) >> 1).astype(np.uint8)
+    params = dict(width=40, height=40, min_valid=0, subpixel=1)
+    flow = dict(flow_x=0.5, flow_y=0.0, count=9, quality=255, flags=1)
+    return prev, cur, params, flow
+
+
+def check_half_pixel(blocks_got, subdirs_got, flow_got, flow):
+    assert len(blocks_got) == 9
+    for b, d in zip(blocks_got, subdirs_got):
+        assert (int(b["dx"]), int(d)) in ((0, 0), (1, 4)) and int(b["dy"]) == 0, (b, d)   # +x from 0 or -x from +1
+    check(blocks_got, flow_got, blocks_got.tolist(), flow)
+
+
 def check(blocks_got, flow_got, blocks, flow):
     want = np.array(blocks, dtype=[("dx", "i1"), ("dy", "i1"), ("sad", "<u2")])
     assert blocks_got.tobytes() == want.tobytes(), (blocks_got, want)
@@ -81,6 +142,8 @@ def all_cases():
     p, c, blocks, plain, starved = case_plain_average_and_min_valid()
     yield p, c, plain[0], blocks, plain[1]
     yield p, c, starved[0], blocks, starved[1]
+    yield case_exposure_step()
+    yield case_two_levels_reach_six_pixels()
 
 
 def test_oracle_reproduces_the_hand_vectors(orc):
@@ -90,14 +153,34 @@ def test_oracle_reproduces_the_hand_vectors(orc):
         check(r["blocks"], r["flow"], blocks, flow)
 
 
+def test_oracle_reproduces_the_half_pixel_vector(orc):
+    prev, cur, params, flow = case_half_pixel()
+    r = orc.flow_pair(orc.default_params(**params), prev, cur)
+    check_half_pixel(r["blocks"], r["subdirs"], r["flow"], flow)
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_the_half_pixel_vector(aof, gpu_device):
+    prev, cur, params, flow = case_half_pixel()
+    p = aof.default_params(40, 40, **{k: v for k, v in params.items() if k not in ("width", "height")})
+    for generic, split in ((False, False), (True, False), (False, True)):
+        eng = aof.FlowEngine(p, 0)
+        eng.force_generic(generic)
+        eng.set_split_coarse(split)
+        got_blocks, got_subdirs, got_flow = eng.flow_pair_host(prev, cur)
+        check_half_pixel(got_blocks, got_subdirs, got_flow, flow)
+        eng.close()
+
+
 @pytest.mark.gpu
 def test_hip_path_reproduces_the_hand_vectors(aof, gpu_device):
     for prev, cur, params, blocks, flow in all_cases():
         w, h = params["width"], params["height"]
         p = aof.default_params(w, h, **{k: v for k, v in params.items() if k not in ("width", "height")})
-        for generic in (False, True):
+        for generic, split in ((False, False), (True, False), (False, True)):   # default / generic / separate kernels
             eng = aof.FlowEngine(p, 0)
             eng.force_generic(generic)
+            eng.set_split_coarse(split)
             got_blocks, _, got_flow = eng.flow_pair_host(prev, cur)
             check(got_blocks, got_flow, blocks, flow)
             eng.close()
