@@ -12,7 +12,8 @@
 //            dy-major, so a wave reads 64 neighbouring windows of one row -- conflict-free
 //            ds_read_b64 -- and 9 * nb items fill 1024 lanes to 99 %; the nine dy rows of a block
 //            meet in an LDS atomicMin on the packed key (sad << 16 | idx) = first minimum wins;
-//   phase 4  writes the level-1 records, votes, and one lane finalises the predictor.
+//   phase 4  writes the level-1 records, votes, and wave 0 finalises the predictor -- while the other
+//            waves already stream the workgroup's next pair (two sets of histograms take turns).
 // HBM traffic: the frames once, 4.5 KB of records and 16 B of predictor per pair.
 //
 // Bound: phase 1 by HBM (2 * W * H bytes per pair), phase 3 by the SAD issue rate; workgroups
@@ -71,8 +72,11 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
     uint8_t *l1[2] = {lds, lds + l1_frame};                 // prev, cur
     uint32_t *keys = reinterpret_cast<uint32_t *>(lds + 2 * l1_frame);
     const int nb = a.grid.blocks();
-    uint32_t *hist = keys + nb;                              // [2][kMaxBins]
-    uint32_t *sums = hist + 2 * kMaxBins;                    // [4] pixel sums, [3] vote sums
+    // Vote histograms [2][kMaxBins] + [4] pixel sums + [3] vote sums, TWICE: consecutive pairs of a
+    // workgroup alternate between the two sets, so that wave 0 can still finalise one pair's flow
+    // record (2 us of dependent divisions) while the other waves already stream the next pair.
+    constexpr int kVoteWords = 2 * kMaxBins + kScratch;
+    uint32_t *votes0 = keys + nb;
     const int tid = threadIdx.x;
 
     // Every workgroup takes the same time, so left alone the whole chip streams (HBM saturated,
@@ -170,13 +174,16 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
         load_batch(p0, p1, 0, A);
         load_batch(p0, p1, kUnroll, B);
     }
-#pragma unroll 1
-    for (int64_t pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
-    const int64_t next = pair + gridDim.x < a.n_pairs ? pair + gridDim.x : pair;   // (last pair: harmless re-reads)
-    LAB_STAMP(0);
-    for (int k = tid; k < 2 * kMaxBins + kScratch; k += kThreads) hist[k] = 0;
-    sum_p0 = sum_p1 = sum_c0 = sum_c1 = 0;
+    for (int k = tid; k < 2 * kVoteWords; k += kThreads) votes0[k] = 0;
     lds_barrier();
+    int par = 0;
+#pragma unroll 1
+    for (int64_t pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x, par ^= 1) {
+    const int64_t next = pair + gridDim.x < a.n_pairs ? pair + gridDim.x : pair;   // (last pair: harmless re-reads)
+    uint32_t *hist = votes0 + par * kVoteWords;              // [2][kMaxBins]
+    uint32_t *sums = hist + 2 * kMaxBins;                    // [4] pixel sums, [3] vote sums
+    LAB_STAMP(0);
+    sum_p0 = sum_p1 = sum_c0 = sum_c1 = 0;
 #pragma unroll 1
     for (int k0 = 0; k0 < nk_pad; k0 += 2 * kUnroll) {
         filter_batch(k0, A);
@@ -206,6 +213,9 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
         uint32_t *c32 = reinterpret_cast<uint32_t *>(l1[1]);
         for (int k = tid; k < l1_frame / 4; k += kThreads) c32[k] = sat_add_u8x4(c32[k], delta);
     }
+    // the other set of histograms and sums is idle by now (its last reader, wave 0 finalising the
+    // previous pair, has passed the barrier above): cleared here for the next pair
+    for (int k = tid; k < kVoteWords; k += kThreads) votes0[(par ^ 1) * kVoteWords + k] = 0;
     const int x0 = a.grid.x0, y0 = a.grid.y0;   // dense grid, step 8: windows start at 8-byte columns
     for (int blk = tid; blk < nb; blk += kThreads) {
         const int by = (int)fast_div((uint32_t)blk, a.div_nx), bx = blk - by * a.grid.nx;
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
     if (tid < 64) finalise_flow_wave(a.tail, pair, hist, hist + kMaxBins, vs);   // (kMaxBins = 64 bins at most)
     LAB_STAMP(5);
     (void)n;
-    lds_barrier();   // lane 0 still reads the histograms the next pair's first step clears
+    // (no barrier: the next pair votes into the other set; this one is cleared two barriers from now)
     }   // next pair of this workgroup
 }
 
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
 
 size_t coarse_lds_bytes(const CoarseArgs &a)
 {
-    return (size_t)2 * (a.w / 2) * (a.h / 2) + (size_t)a.grid.blocks() * 4 + (2 * kMaxBins + kScratch) * 4;
+    return (size_t)2 * (a.w / 2) * (a.h / 2) + (size_t)a.grid.blocks() * 4 + 2 * (2 * kMaxBins + kScratch) * 4;
 }
 
 // One workgroup must hold both level-1 frames, and the windows must sit on 8-byte columns.
