@@ -30,9 +30,20 @@ int main(int argc, char **argv)
     std::vector<uint8_t> h(frame * 8);
     srand(1);
     for (size_t i = 0; i < h.size(); i++) h[i] = (uint8_t)((rand() & 0x7F) + 40 + ((i / 7) & 31));
+    if (argc > 4 && atoi(argv[4]) != 0)   // smooth the lab frames a little, so that the level-1 tiles match their moved copies
+        for (size_t i = 1; i + 1 < h.size(); i++) h[i] = (uint8_t)((h[i - 1] + 2 * h[i] + h[i + 1]) / 4);
+    const bool match = argc > 4 && atoi(argv[4]) != 0;   // cur = prev moved by (+4, -2): real matches, uniform votes (the bench's case)
+    std::vector<uint8_t> moved(frame);
     for (int i = 0; i < n; i++) {
-        CHECK(hipMemcpy(d_prev + frame * i, h.data() + frame * (i % 8), frame, hipMemcpyHostToDevice));
-        CHECK(hipMemcpy(d_cur + frame * i, h.data() + frame * ((i + 3) % 8), frame, hipMemcpyHostToDevice));
+        const uint8_t *pf = h.data() + frame * (i % 8);
+        CHECK(hipMemcpy(d_prev + frame * i, pf, frame, hipMemcpyHostToDevice));
+        if (match) {
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) moved[(size_t)y * W + x] = pf[(size_t)((y + 2) % H) * W + (x + W - 4) % W];
+            CHECK(hipMemcpy(d_cur + frame * i, moved.data(), frame, hipMemcpyHostToDevice));
+        } else {
+            CHECK(hipMemcpy(d_cur + frame * i, h.data() + frame * ((i + 3) % 8), frame, hipMemcpyHostToDevice));
+        }
     }
     CoarseArgs a{};
     a.prev = d_prev; a.cur = d_cur; a.pair_stride = (int64_t)frame; a.w = W; a.h = H;
