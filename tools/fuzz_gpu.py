@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Long differential fuzz on a GPU box (not part of the test suite): random geometry, options
 and image statistics; default, strip-kernel, pruned, generic and separate-kernel device paths against the CPU oracle.
-    python tools/fuzz_gpu.py [n_cases] [first_seed]"""
+    python tools/fuzz_gpu.py [n_cases] [first_seed]            random configurations, two pairs per call
+    python tools/fuzz_gpu.py [n_cases] [first_seed] many       the persistent coarse kernel: hundreds of pairs per call"""
 import importlib
 import os
 import sys
@@ -76,9 +77,65 @@ def case(rng):
                 min_valid=int(rng.choice([0, 10, 10, 500])), num_blocks=int(rng.integers(2, 9)))
 
 
+def many_pairs(n_cases, seed0):
+    """The fused coarse kernel (k_coarse) is persistent: a workgroup walks pairs i, i + CUs, ... and lets
+    the next pair's stream phase start under the current pair's last step.  Two pairs per call never get
+    there: these cases run several hundred small dense two-level pairs per call, every pair against the
+    oracle, the workspace's level-1 flows and sums against the separate kernels."""
+    dev = torch.device("cuda:0")
+    t0 = time.time()
+    for s in range(seed0, seed0 + n_cases):
+        rng = np.random.default_rng(770000 + s)
+        w, h = 16 * int(rng.integers(4, 13)), 2 * int(rng.integers(26, 70))
+        kw = dict(width=w, height=h, pyramid_levels=2, mean_subtract=int(rng.integers(0, 2)), hist_filter=int(rng.integers(0, 2)),
+                  feature_threshold=int(rng.choice([0, 30, 200])), value_threshold=int(rng.choice([500, 3000, 70000])),
+                  min_valid=int(rng.choice([0, 10])))
+        p = aof.default_params(**kw)
+        if aof.check_params(p) != 0:
+            continue
+        k, n = 12, int(rng.integers(300, 900))
+        hp, hc, _ = synth.make_batch(w, h, k, 9, 660000 + 5 * s, noise=int(rng.choice([0, 3, 25])),
+                                     brightness=int(rng.integers(-30, 31)))
+        ip, ic = rng.integers(0, k, n), rng.integers(0, k, n)
+        same = rng.random(n) < 0.7
+        ic = np.where(same, ip, ic)          # most pairs match, some compare unrelated frames
+        prevs, curs = hp[ip], hc[ic]
+        po = orc.params_from(p)
+        cache = {}
+        tp, tc = torch.from_numpy(prevs).to(dev), torch.from_numpy(curs).to(dev)
+        outs = []
+        for split in (False, True):
+            eng = aof.FlowEngine(p, 0)
+            eng.set_split_coarse(split)
+            blocks, flows, ws = eng.flow_batch(tp, tc)
+            torch.cuda.synchronize()
+            L = aof.workspace_layout(p, n)
+            wsn = ws.cpu().numpy()
+            outs.append((aof.blocks_view(blocks).copy(), aof.flows_view(flows).copy(), wsn[L.l1_flows:L.l1_flows + 16 * n].tobytes(),
+                         wsn[L.sums:L.sums + 16 * n].tobytes() if p.mean_subtract else b""))
+            eng.close()
+        gb, gf = outs[0][0], outs[0][1]
+        for i in range(n):
+            key = (int(ip[i]), int(ic[i]))
+            if key not in cache:
+                cache[key] = orc.flow_pair(po, prevs[i], curs[i])
+            ref = cache[key]
+            if gb[i].tobytes() != ref["blocks"].tobytes() or gf[i].tobytes() != ref["flow"].tobytes():
+                print(f"MISMATCH many-pairs seed {s} pair {i} of {n}: {kw}", flush=True)
+                sys.exit(1)
+        if outs[0][2] != outs[1][2] or outs[0][3] != outs[1][3] or outs[0][1].tobytes() != outs[1][1].tobytes():
+            print(f"MISMATCH many-pairs seed {s}: fused and separate kernels differ in the workspace: {kw}", flush=True)
+            sys.exit(1)
+        if (s - seed0 + 1) % 20 == 0:
+            print(f"{s - seed0 + 1} many-pairs cases ok ({time.time() - t0:.0f} s)", flush=True)
+    print(f"many-pairs fuzz passed: {n_cases} cases of 300..900 pairs per call, {time.time() - t0:.0f} s")
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if len(sys.argv) > 3 and sys.argv[3] == "many":
+        return many_pairs(n_cases, seed0)
     dev = torch.device("cuda:0")
     t0, done, skipped, variants = time.time(), 0, 0, {}
     for s in range(seed0, seed0 + n_cases):
