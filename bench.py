@@ -166,6 +166,17 @@ def bench_c1(args, aof, rank, world, dist):
            "config": {"workload": "C1 64x64 frames, PX4Flow 5x5 sparse grid, facade OpticalFlowPX4::calcFlow, "
                                   "host buffers (PCIe-inclusive)", "calls_per_step": calls,
                       "us_per_call": round(elapsed / (args.steps * calls) * 1e6, 2)}}
+    # the class mainloop.cpp:423 actually creates, at the reference's default crop (main.cpp:57-58):
+    # OpticalFlowOpenCV, 128x128, two levels + mean equalisation
+    frames2, _ = synth.make_sequence(128, 128, 64, 8, seed=2, max_step=6)
+    flow2 = aof.OpticalFlowOpenCV(216.6677, 216.2457, 15, 128, 128)
+    for k in range(200):
+        flow2.calcFlow(frames2[k & 63], (k * 13333) & 0xFFFFFFFF)
+    t0 = time.perf_counter()
+    n2 = max(1000, calls)
+    for k in range(n2):
+        flow2.calcFlow(frames2[k & 63], ((200 + k) * 13333) & 0xFFFFFFFF)
+    out["config"]["opencv_facade_128x128_two_levels_us_per_call"] = round((time.perf_counter() - t0) / n2 * 1e6, 2)
     if rank == 0:
         from oracle import pyoracle as orc
         o = orc.Px4(orc.px4flow_params(64, 64), 216.6677, 216.2457, 15)
