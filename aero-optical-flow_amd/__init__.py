@@ -100,6 +100,7 @@ def _load():
         "aof_set_search_mode": (C.c_int, [VP, C.c_int]),
         "aof_set_pipeline": (C.c_int, [VP, I64]),
         "aof_set_split_coarse": (C.c_int, [VP, C.c_int]),
+        "aof_set_reduce_fusion": (C.c_int, [VP, C.c_int]),
         "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
         "aof_flow_pair_host": (C.c_int, [VP, VP, VP, VP, VP, VP]),
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
@@ -264,6 +265,12 @@ class FlowEngine:
         workspace's level-1 frames) instead of the fused coarse kernel."""
         self._check(lib.aof_set_split_coarse(self._ctx, int(on)))
 
+    def set_reduce_fusion(self, on=True):
+        """8x8 tiles on large grids: reduce inside the search launch (default) or launch K3 separately."""
+        if not hasattr(lib, "aof_set_reduce_fusion"):
+            return   # (AOF_LIB pointing at an older build)
+        self._check(lib.aof_set_reduce_fusion(self._ctx, int(on)))
+
     def set_pipeline(self, sub_pairs):
         """Two-level batches: pairs per pipelined sub-batch (0 = off, < 0 = automatic, the default)."""
         if int(sub_pairs) == 0 and not hasattr(lib, "aof_set_pipeline"):
@@ -334,6 +341,34 @@ class FlowEngine:
             subdirs.data_ptr() if subdirs is not None else None, flows.data_ptr(),
             workspace.data_ptr(), workspace.numel(), stream))
         return blocks, flows, workspace
+
+    def bind_batch(self, prev, cur, blocks, flows, workspace, subdirs=None, stream=None):
+        """flow_batch with every argument resolved once: returns a callable that enqueues the same
+        batch on torch's current stream (or on `stream`, a hipStream_t value) with ONE ctypes call (a step of 128 VGA pairs takes 35 us on
+        the device; flow_batch's own argument handling takes about as long on the host)."""
+        import torch
+        p = self.params
+        n_pairs = prev.shape[0]
+        stride = prev.stride(0) if prev.dim() == 3 else p.width * p.height
+        assert workspace.numel() >= workspace_layout(p, n_pairs).total_bytes
+        args = (self._ctx, prev.data_ptr(), cur.data_ptr(), stride, n_pairs, blocks.data_ptr(),
+                subdirs.data_ptr() if subdirs is not None else None, flows.data_ptr(),
+                workspace.data_ptr(), workspace.numel())
+        keep = (prev, cur, blocks, flows, workspace, subdirs)
+        fn, dev, current_stream = lib.aof_flow_batch_device, prev.device, torch.cuda.current_stream
+
+        if stream is not None:   # a fixed hipStream_t (0 = the default stream)
+            def enqueue():
+                rc = fn(*args, stream)
+                if rc < 0:
+                    self._check(rc)
+        else:
+            def enqueue():
+                rc = fn(*args, current_stream(dev).cuda_stream)
+                if rc < 0:
+                    self._check(rc)
+        enqueue.keep = keep
+        return enqueue
 
     # -- host buffers -----------------------------------------------------------
     def flow_pair_host(self, prev: np.ndarray, cur: np.ndarray):

@@ -58,8 +58,17 @@ struct aof_ctx {
     hipEvent_t *pipe_ev;        // [kPipeEvents]: fork + per-sub-batch coarse-done / fine-done
     int64_t pipeline_pairs;     // sub-batch size: 0 = off, < 0 = automatic
     bool split_coarse;          // run K1 / level-1 search / level-1 reduce as separate kernels
+    // reduction inside the flat lane8 search (no K3 launch): the pairs' vote records, zero at rest
+    uint32_t *d_votes;
+    int64_t votes_pairs;        // records allocated
+    bool separate_reduce;       // aof_set_reduce_fusion(ctx, 0): always launch K3
+    hipEvent_t votes_done;      // recorded behind every launch that uses d_votes
+    hipStream_t votes_stream;   // stream of that launch
+    bool votes_used;
 };
 
+constexpr int64_t kVotePairs = 8192;             // vote records per context (launches of more pairs keep K3)
+constexpr uint32_t kVoteStride = 128;            // words per record: 1 + 2 * 55 bins at the most (R = 13)
 constexpr int kPipeMaxSub = 64;                  // sub-batches per call at most
 constexpr int kPipeEvents = 1 + 2 * kPipeMaxSub;
 
@@ -175,9 +184,29 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, uint32_t *parts
         rc = launch_flow_lane8(a, tail, s);
         *reduced = true;
         break;
-    case SK_LANE8:
-        rc = launch_search_lane8(a, s);
+    case SK_LANE8: {
+        // search + reduction in one launch when the context's vote memory can serve it; launches on
+        // another stream than the last one wait for that one first (the records are shared)
+        const VoteMem vm = {ctx->d_votes, kVoteStride};
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (ctx->separate_reduce || ctx->force_generic || !lane8_votes_supported(a, vm, ctx->votes_pairs) ||
+            hipStreamIsCapturing(s, &cap) != hipSuccess) {
+            rc = launch_search_lane8(a, s);
+            break;
+        }
+        const bool eager = cap == hipStreamCaptureStatusNone;
+        if (eager && ctx->votes_used && ctx->votes_stream != s &&
+            hipStreamWaitEvent(s, ctx->votes_done, 0) != hipSuccess)
+            return fail(ctx, -EIO, "cannot order the launch behind the context's previous one");
+        rc = launch_search_lane8(a, s, &tail, &vm);
+        if (!rc && eager) {
+            rc = (int)hipEventRecord(ctx->votes_done, s);
+            ctx->votes_stream = s;
+            ctx->votes_used = true;
+        }
+        *reduced = true;
         break;
+    }
     default:
         rc = launch_search_generic(a, s);
     }
@@ -333,6 +362,19 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
         if (!ok) { aof_destroy(ctx); return -EIO; }
     }
 
+    if (p->tile == 8 && p->search == 4) {   // the flat lane8 search can reduce in its own launch
+        DeviceGuard guard(device);
+        const size_t bytes = (size_t)kVotePairs * kVoteStride * sizeof(uint32_t);
+        if (hipMalloc((void **)&ctx->d_votes, bytes) != hipSuccess || hipMemset(ctx->d_votes, 0, bytes) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->votes_done, hipEventDisableTiming) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+            aof_destroy(ctx);
+            return -EIO;
+        }
+        ctx->votes_pairs = kVotePairs;
+    }
+    ctx->separate_reduce = true;   // the in-launch reduction is opt-in (aof_set_reduce_fusion)
+
     *out = ctx;
     return 0;
 }
@@ -365,6 +407,8 @@ void aof_destroy(aof_ctx *ctx)
     if (ctx->d_subdirs) (void)hipFree(ctx->d_subdirs);
     if (ctx->d_flow) (void)hipFree(ctx->d_flow);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->votes_done) { (void)hipEventSynchronize(ctx->votes_done); (void)hipEventDestroy(ctx->votes_done); }
+    if (ctx->d_votes) (void)hipFree(ctx->d_votes);
     delete ctx;
 }
 
@@ -578,6 +622,13 @@ int aof_set_split_coarse(aof_ctx *ctx, int on)
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
     ctx->split_coarse = on != 0;
+    return 0;
+}
+
+int aof_set_reduce_fusion(aof_ctx *ctx, int on)
+{
+    if (!ctx) return -EINVAL;
+    ctx->separate_reduce = on == 0;
     return 0;
 }
 

@@ -63,6 +63,13 @@ struct FlowTail {
     int32_t emit_predictor;    // level 1: write the integer predictor into pred_x/pred_y
 };
 
+// The context's vote memory (zero at rest): one record per pair of the running launch -- word 0 the
+// number of blocks that have arrived, then the two vote histograms (aof_reduce.hpp).
+struct VoteMem {
+    uint32_t *base;     // [pairs][stride] words
+    uint32_t stride;    // words per pair, a multiple of 64 (256 bytes: pairs never share a line)
+};
+
 // Everything one search launch needs; passed to the kernels by value.
 struct SearchArgs {
     const uint8_t *prev;       // level frames of the older image, pair i at +i*stride
@@ -153,7 +160,11 @@ int launch_search_tile8(const SearchArgs &a, void *stream);
 // predictor (sparse PX4Flow grid, rows that are no multiple of 16 bytes), half-pixel refinement
 // included.
 bool lane8_supported(const SearchArgs &a);
-int launch_search_lane8(const SearchArgs &a, void *stream);
+// tail + votes: the reduction runs inside the same launch (votes through agent-scope atomics into the
+// context's vote memory, the last wave of a pair writes its flow record); no K3 follows.
+bool lane8_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t capacity_pairs);
+int launch_search_lane8(const SearchArgs &a, void *stream, const FlowTail *tail = nullptr,
+                        const VoteMem *votes = nullptr);
 // Grids of 8..256 blocks: a workgroup owns whole pairs and also writes their flow records (no K3).
 int lane8_group(const SearchArgs &a);  // pairs per workgroup, 0 = not applicable
 int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream);

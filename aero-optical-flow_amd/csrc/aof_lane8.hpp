@@ -183,10 +183,17 @@ __device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint3
 struct PairMeta { int px, py, delta; };
 
 template <bool SUBPIXEL, bool PRUNE, bool EQ = true>
-__device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, uint32_t blk, uint32_t item, bool live,
+__device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, uint32_t blk, uint32_t item0, bool live,
                                             aof_block &rec, int &start_row, int &prune_pays,
                                             const PairMeta *given = nullptr)
 {
+    // item = item0 + threadIdx.x (item0 uniform in the workgroup): index of the block's record.  It is
+    // derived again from the lane id wherever it is needed, so it holds no register during the search.
+    auto record_slot = [&]() -> uint32_t {
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return item0 + t;
+    };
     // (blocks, grid coordinates and pixel offsets stay below 2^24 -- aof_params_check limits a frame to
     //  2^24 pixels --, so the products are full-rate 24-bit multiplies, not quarter-rate 32-bit ones)
     const uint32_t by = fast_div(blk, a.div_nx), bx = blk - __umul24(by, (uint32_t)a.grid.nx);
@@ -242,13 +249,14 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
         }
     }
     rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
-    uint32_t *out = reinterpret_cast<uint32_t *>(a.blocks) + item;  // one dword store per record
+    uint32_t *const slots = reinterpret_cast<uint32_t *>(a.blocks);  // one dword store per record
     // the search window (plus the half-pixel ring) must lie inside the frame
     const int wx0 = i + px - 4, wy0 = j + py - 4;
     const bool inside = live && !(wx0 - m < 0 || wy0 - m < 0 || wx0 + 16 + m > a.w || wy0 + 16 + m > a.h);
     if (!PRUNE && !inside) {
         if (live) {
-            *out = __builtin_bit_cast(uint32_t, rec);
+            const uint32_t item = record_slot();
+            slots[item] = __builtin_bit_cast(uint32_t, rec);
             if (SUBPIXEL) a.subdirs[item] = 8;
         }
         return 8;
@@ -274,7 +282,8 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
     if (inside) gradient = gradient_gate(ref);
     const bool need = inside && gradient >= (uint32_t)a.feature_threshold;
     if (!PRUNE && !need) {
-        *out = __builtin_bit_cast(uint32_t, rec);
+        const uint32_t item = record_slot();
+        slots[item] = __builtin_bit_cast(uint32_t, rec);
         if (SUBPIXEL) a.subdirs[item] = 8;
         return 8;
     }
@@ -301,7 +310,8 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
         }
         if (!need) {
             if (live) {
-                *out = __builtin_bit_cast(uint32_t, rec);
+                const uint32_t item = record_slot();
+                slots[item] = __builtin_bit_cast(uint32_t, rec);
                 if (SUBPIXEL) a.subdirs[item] = 8;
             }
             return 8;
@@ -313,7 +323,8 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
     rec.dx = (int8_t)(px + idx % 9 - 4);
     rec.dy = (int8_t)(py + idx / 9 - 4);
     rec.sad = (uint16_t)(best >> 16);
-    *out = __builtin_bit_cast(uint32_t, rec);
+    const uint32_t item = record_slot();
+    slots[item] = __builtin_bit_cast(uint32_t, rec);
 
     // Half-pixel refinement of accepted blocks: the ring of the best match, rows -1..8 and
     // bytes -1..8, again straight from global memory (the lines were touched a moment ago).

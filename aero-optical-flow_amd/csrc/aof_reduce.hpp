@@ -89,13 +89,29 @@ __device__ __forceinline__ void write_flow(const FlowTail &a, int64_t pair, int 
 // reads (2 us for 19 bins) while its workgroup -- in k_coarse the whole CU -- waits.  n <= 64.
 // record_out (optional, LDS): lane 0 also leaves the record there; pred_rec (optional): the level-1
 // record to copy the predictor fields from, instead of a.pred[pair] in global memory.
+__device__ __forceinline__ void finalise_flow_wave_bins(const FlowTail &a, int64_t pair, uint32_t hx, uint32_t hy,
+                                                        int sum2x, int sum2y, int total, aof_flow *record_out = nullptr,
+                                                        const aof_flow *pred_rec = nullptr);
+
 __device__ __forceinline__ void finalise_flow_wave(const FlowTail &a, int64_t pair, const uint32_t *hist_x,
                                                    const uint32_t *hist_y, const int *sums, aof_flow *record_out = nullptr,
                                                    const aof_flow *pred_rec = nullptr)
 {
+    const int n = 2 * (2 * a.range + 1) + 1;
+    const int k = (int)(threadIdx.x & 63);
+    finalise_flow_wave_bins(a, pair, k < n ? hist_x[k] : 0u, k < n ? hist_y[k] : 0u, sums[0], sums[1], sums[2],
+                            record_out, pred_rec);
+}
+
+// The same with the bins already in registers: lane k brings bin k of both histograms (0 for k >= n);
+// sum2x / sum2y / total (wave-uniform): the sums of the 2*dx and 2*dy votes and their number.
+__device__ __forceinline__ void finalise_flow_wave_bins(const FlowTail &a, int64_t pair, uint32_t hx, uint32_t hy,
+                                                        int sum2x, int sum2y, int total, aof_flow *record_out,
+                                                        const aof_flow *pred_rec)
+{
     const int centre = 2 * a.range + 1, n = 2 * centre + 1;
     const int k = (int)(threadIdx.x & 63);
-    const uint32_t hx = k < n ? hist_x[k] : 0u, hy = k < n ? hist_y[k] : 0u;
+    const int sums[3] = {sum2x, sum2y, total};
     uint32_t mx = hx, my = hy;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -124,12 +140,14 @@ __device__ __forceinline__ void finalise_flow_wave(const FlowTail &a, int64_t pa
 #pragma clang fp contract(off)
         if (a.hist_filter) {
             flow = (__fdiv_rn((float)v, (float)w) - (float)centre) / 2.0f;
-            pred = small ? floor_div<int>((int)(2 * v + w), (int)(2 * w)) - centre
-                         : (int)(floor_div<long long>(2ll * v + w, 2ll * w) - centre);
+            if (a.emit_predictor)   // (uniform; the integer division is as long as everything else here)
+                pred = small ? floor_div<int>((int)(2 * v + w), (int)(2 * w)) - centre
+                             : (int)(floor_div<long long>(2ll * v + w, 2ll * w) - centre);
         } else {
             flow = __fdiv_rn((float)s2 * 0.5f, (float)count);
-            pred = small ? floor_div<int>(2 * s2 + (int)count, 2 * (int)count)
-                         : (int)floor_div<long long>(2ll * s2 + count, 2ll * count);
+            if (a.emit_predictor)
+                pred = small ? floor_div<int>(2 * s2 + (int)count, 2 * (int)count)
+                             : (int)floor_div<long long>(2ll * s2 + count, 2ll * count);
         }
     }
     const float flow_y = __shfl(flow, 1, 64);
@@ -158,6 +176,123 @@ __device__ __forceinline__ void finalise_flow_wave(const FlowTail &a, int64_t pa
         a.flows[pair] = out;
         if (record_out) *record_out = out;
     }
+}
+
+// ---- votes in global memory: the reduction inside the search kernel (no K3 launch) ----------------
+// A pair's votes meet in a small record of the context's own vote memory (aof_ctx::d_votes, zero at
+// rest): a 64-bit arrival word -- high half the number of blocks that have arrived, low half the number
+// of votes they cast -- followed by the two histograms.  SEARCH waves add their votes (aggregated across
+// the wave first: under a global motion two adds per wave) and then their arrival with agent-scope
+// integer atomics WITHOUT waiting for any of them: nothing is returned, the wave ends at once.  The
+// launch carries one extra FINALISER wave per pair behind its search workgroups; it reads arrival word
+// and bins (agent-scope loads) until all blocks have arrived AND both histograms hold as many votes as
+// the arrival word announces -- counts only grow, so equal sums mean every add has landed, in whatever
+// order the memory system performed them -- then writes the pair's aof_flow and zeroes the record for
+// the next launch.  Integer adds commute: the flow record does not depend on arrival order.
+// No deadlock: a finaliser only waits for search waves, search waves wait for nothing, and a
+// finaliser's workgroup id is higher than that of every search workgroup, so all search workgroups of
+// its XCD have been dispatched before it occupies a slot.  Nothing here needs a cache write-back or
+// invalidate: the record is only ever touched by agent-scope atomics, which are performed beyond the
+// XCDs' L2s (an agent-scope RELEASE per workgroup, which records in ordinary memory would need, costs
+// an L2 write-back each and made the kernel 4x slower: round 1; a last-arriver scheme, in which every
+// search wave waits for its adds and an arrival counter, cost 14 % of the search: round 3).
+__device__ __forceinline__ void vote_add_agent(uint32_t *p, uint32_t v)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // result unused: no return, no wait
+}
+
+// One axis: one add per distinct bin among the lanes in `active` (called by the whole wave).
+__device__ __forceinline__ void wave_vote_agent(uint32_t *hist, int bin, bool active)
+{
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bin, leader, 64);
+        const unsigned long long same = __ballot(active && bin == b) & todo;
+        if ((int)(threadIdx.x & 63) == leader) vote_add_agent(&hist[b], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+// Search side, called by ALL 64 lanes of a wave.  `member`: the lane's block belongs to `pair`
+// (wave-uniform pair); `ok`: it votes, for bins (bin_x, bin_y).
+__device__ __forceinline__ void vote_and_arrive(const VoteMem &vm, int range, uint32_t pair, bool member, bool ok,
+                                                int bin_x, int bin_y)
+{
+    const unsigned long long members = __ballot(member);
+    if (members == 0) return;   // (wave-uniform)
+    const int n = 2 * (2 * range + 1) + 1, lane = (int)(threadIdx.x & 63);
+    uint32_t *rec = vm.base + (size_t)pair * vm.stride, *hist_x = rec + 2, *hist_y = rec + 2 + n;
+    ok = ok && member;
+    const unsigned long long voters = __ballot(ok);
+    if (voters) {
+        const int key = bin_x | (bin_y << 8);
+        const int first = __ffsll((long long)voters) - 1;
+        const int k = __shfl(key, first, 64);
+        if ((__ballot(ok && key == k) & voters) == voters) {   // one motion in the whole wave: two adds
+            if (lane == first) {
+                const uint32_t c = (uint32_t)__popcll(voters);
+                vote_add_agent(&hist_x[k & 0xFF], c);
+                vote_add_agent(&hist_y[k >> 8], c);
+            }
+        } else {
+            wave_vote_agent(hist_x, bin_x, ok);
+            wave_vote_agent(hist_y, bin_y, ok);
+        }
+    }
+    if (lane == __ffsll((long long)members) - 1)
+        (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(rec),
+                                     ((unsigned long long)__popcll(members) << 32) | (unsigned long long)__popcll(voters),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Finaliser side: ONE WAVE per pair (all 64 lanes), n <= 62.  Gives up after `deadline_ticks` of the
+// 100 MHz real-time counter (a search wave that never arrives means the launch is broken anyway): the
+// record is zeroed all the same and the flow record is written as all ones, which no valid result is.
+__device__ __forceinline__ void await_votes_and_finalise(const VoteMem &vm, const FlowTail &tail, uint32_t pair,
+                                                         uint64_t deadline_ticks)
+{
+    const int centre = 2 * tail.range + 1, n = 2 * centre + 1, lane = (int)(threadIdx.x & 63);
+    uint32_t *rec = vm.base + (size_t)pair * vm.stride, *hist_x = rec + 2, *hist_y = rec + 2 + n;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t hx = 0, hy = 0;
+    int total = 0;
+    bool complete = false;
+    for (;;) {
+        uint32_t arrived = 0, announced = 0;
+        if (lane < n) {
+            hx = __hip_atomic_load(&hist_x[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hy = __hip_atomic_load(&hist_y[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 63) {
+            const unsigned long long a = __hip_atomic_load(reinterpret_cast<unsigned long long *>(rec), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            arrived = (uint32_t)(a >> 32);
+            announced = (uint32_t)a;
+        }
+        arrived = (uint32_t)__shfl((int)arrived, 63, 64);
+        announced = (uint32_t)__shfl((int)announced, 63, 64);
+        total = (int)wave_sum_u32(hx);
+        complete = arrived == (uint32_t)tail.nblocks && (uint32_t)total == announced && wave_sum_u32(hy) == announced;
+        if (complete || __builtin_amdgcn_s_memrealtime() - t0 > deadline_ticks) break;   // (wave-uniform)
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (lane < n) {   // zero at rest
+        __hip_atomic_store(&hist_x[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hist_y[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (lane == 63) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(rec), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!complete) {
+        if (lane == 0) {
+            aof_flow bad;
+            __builtin_memset(&bad, 0xFF, sizeof(bad));
+            tail.flows[pair] = bad;
+        }
+        return;
+    }
+    const int sum2x = (int)wave_sum_u32((uint32_t)((lane - centre) * (int)hx));
+    const int sum2y = (int)wave_sum_u32((uint32_t)((lane - centre) * (int)hy));
+    finalise_flow_wave_bins(tail, (int64_t)pair, hx, hy, sum2x, sum2y, total);
 }
 
 // hist_x/hist_y: n = 2*(2R+1)+1 bins each; sums = {sum of 2*dx votes, sum of 2*dy votes, count}.

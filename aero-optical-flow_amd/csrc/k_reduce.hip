@@ -22,12 +22,16 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxHist = 256;
 constexpr int kBatch = 10;  // record loads in flight per lane
+#ifndef AOF_REDUCE_WIDE_PAIRS
+#define AOF_REDUCE_WIDE_PAIRS 512
+#endif
+constexpr int64_t kWidePairs = AOF_REDUCE_WIDE_PAIRS;   // up to here a pair gets 1024 lanes instead of 256
 
 // GROUP = threads per pair: 256 (one workgroup per pair) or 64 (one wave per pair, four pairs
 // per workgroup: sparse grids with a few dozen blocks per pair, where a whole workgroup per
 // pair is mostly launch overhead).  A wave-sized group needs no workgroup barrier: its LDS
 // operations retire in program order.
-template <int GROUP>
+template <int GROUP, int kThreads = 256>
 __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
 {
     constexpr int kGroups = kThreads / GROUP;
@@ -167,6 +171,11 @@ int launch_reduce(const ReduceArgs &a, void *stream)
     }
     if (a.tail.nblocks <= 256 && !a.parts)  // sparse grids: one wave per pair
         hipLaunchKernelGGL(k_reduce<64>, dim3((uint32_t)((a.n_pairs + 3) / 4)), dim3(kThreads), 0,
+                           static_cast<hipStream_t>(stream), a);
+    else if (a.n_pairs <= kWidePairs && a.tail.nblocks >= 2048 && !a.parts)
+        // few pairs of many blocks (configs[3]'s per-GPU share: 128 VGA pairs on 256 CUs): the launch is
+        // latency-bound -- sixteen waves per pair fetch its records in ONE round trip
+        hipLaunchKernelGGL((k_reduce<1024, 1024>), dim3((uint32_t)a.n_pairs), dim3(1024), 0,
                            static_cast<hipStream_t>(stream), a);
     else
         hipLaunchKernelGGL(k_reduce<kThreads>, dim3((uint32_t)a.n_pairs), dim3(kThreads), 0,

@@ -41,8 +41,9 @@ constexpr int kThreads = 256;  // 64, 128 and 256 measure the same, 512 is 4 % s
 // the other three waves of the SIMD cover that round trip.
 // PRUNE: a workgroup walks `spw` consecutive 256-item chunks (block rows further down the same
 // frame) and each wave carries the dy row where its previous chunk matched.
-template <bool SUBPIXEL, bool PRUNE, bool EQ>
-__device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t items, uint32_t total_wgs, int spw)
+template <bool SUBPIXEL, bool PRUNE, bool EQ, bool VOTE = false>
+__device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t items, uint32_t total_wgs, int spw,
+                                              const FlowTail *tail = nullptr, const VoteMem *votes = nullptr)
 {
     // consecutive workgroups = consecutive block rows of one pair: keep them on one XCD, whose L2
     // then serves the search rows that vertically adjacent blocks share
@@ -50,16 +51,39 @@ __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t item
     const uint32_t nb = (uint32_t)a.grid.blocks();
     int start_row = 4, prune_pays = 1;
     for (int c = 0; c < spw; c++) {
-        const uint32_t item0 = (wg * (uint32_t)spw + (uint32_t)c) * kThreads;   // < 2^31 (launcher)
+        const uint32_t item0 = (wg * (uint32_t)spw + (uint32_t)c) * blockDim.x;   // < 2^31 (launcher)
         const uint32_t item = item0 + threadIdx.x;
         const bool live = item < items;
-        if (!PRUNE && !live) return;
+        if (!PRUNE && !VOTE && !live) return;
         if (PRUNE && item0 >= items) return;   // whole workgroup past the end (uniform)
         const uint32_t pair = live ? fast_div(item, a.div_nb) : 0u;
         aof_block rec;
         rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
-        (void)search_block<SUBPIXEL, PRUNE, EQ>(a, pair, live ? item - __umul24(pair, nb) : 0u, item, live, rec, start_row,
-                                            prune_pays);
+        const int subdir = search_block<SUBPIXEL, PRUNE, EQ>(a, pair, live ? item - __umul24(pair, nb) : 0u, item0, live,
+                                                             rec, start_row, prune_pays);
+        if constexpr (VOTE) {
+            // The reduction in the same launch: every lane stays until here and the wave adds its votes
+            // to the records of the one or two pairs it covers (a pair has more than 64 blocks), without
+            // waiting for anything (aof_reduce.hpp).  Item and pair are derived again from an
+            // opaque copy of the lane id, so that none of it occupies a register during the search
+            // (the kernel sits at the 128 VGPRs of four waves per SIMD).
+            uint32_t lane_id = threadIdx.x;
+            asm volatile("" : "+v"(lane_id));
+            const uint32_t item2 = item0 + lane_id;
+            const bool live2 = item2 < items;
+            const uint32_t pair2 = live2 ? fast_div(item2, a.div_nb) : 0u;
+            const bool ok = live2 && (uint32_t)rec.sad < (uint32_t)a.value_threshold;   // skipped = 0xFFFF
+            int hx = 0, hy = 0;
+            if (SUBPIXEL) {
+                hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
+                hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
+            }
+            const int centre = 2 * a.hist_range + 1;
+            const int bin_x = 2 * rec.dx + hx + centre, bin_y = 2 * rec.dy + hy + centre;
+            const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair2);   // lane 0 is live or the wave is empty
+            vote_and_arrive(*votes, a.hist_range, lead, live2 && pair2 == lead, ok, bin_x, bin_y);
+            vote_and_arrive(*votes, a.hist_range, lead + 1, live2 && pair2 != lead, ok, bin_x, bin_y);
+        }
     }
 }
 
@@ -67,6 +91,33 @@ template <bool SUBPIXEL, bool EQ>
 __global__ __launch_bounds__(kThreads, 4) void k_search_lane8(SearchArgs a, uint32_t items, uint32_t total_wgs, int spw)
 {
     search_chunks<SUBPIXEL, false, EQ>(a, items, total_wgs, spw);
+}
+
+// The same search with the reduction in the launch: no K3 behind it.  Workgroups [0, search_wgs) search
+// and vote through agent-scope atomics; the workgroups behind them are finalisers, one wave per pair,
+// which wait for their pair's votes and write its flow record (aof_reduce.hpp).
+constexpr uint64_t kVoteDeadlineTicks = 5000000;   // 50 ms of the 100 MHz counter
+
+template <bool SUBPIXEL, bool EQ>
+__global__ __launch_bounds__(kThreads, 4) void k_flow_lane8_flat(SearchArgs a, uint32_t items, uint32_t search_wgs,
+                                                                 FlowTail tail, VoteMem votes)
+{
+    if (blockIdx.x >= search_wgs) {   // (uniform in the workgroup)
+        const uint32_t pair = (blockIdx.x - search_wgs) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (pair < (uint32_t)a.n_pairs) await_votes_and_finalise(votes, tail, pair, kVoteDeadlineTicks);
+        return;
+    }
+    // Every kernel argument the search reads, fetched HERE in one batch of scalar loads: with the
+    // finaliser branch above, the compiler otherwise sinks them into the blocks that use them -- seven
+    // dependent s_load / s_waitcnt round trips in front of the row loads of every wave (+7 % on the
+    // 1 024-pair launch).
+    asm volatile("" ::"s"(a.prev), "s"(a.cur), "s"(a.pair_stride), "s"(a.w), "s"(a.h), "s"(a.grid.x0), "s"(a.grid.y0),
+                 "s"(a.grid.step_x), "s"(a.grid.step_y), "s"(a.grid.nx), "s"(a.grid.ny), "s"(a.feature_threshold),
+                 "s"(a.value_threshold));
+    asm volatile("" ::"s"(a.blocks), "s"(a.subdirs), "s"(a.pred), "s"(a.sums), "s"(a.level), "s"(a.n_pairs),
+                 "s"(a.hist_range), "s"(a.div_nb.mul), "s"(a.div_nb.shift), "s"(a.div_nx.mul), "s"(a.div_nx.shift),
+                 "s"(items), "s"(votes.base), "s"(votes.stride));
+    search_chunks<SUBPIXEL, false, EQ, true>(a, items, search_wgs, 1, &tail, &votes);
 }
 
 // The pruned search holds both code paths (pruned rows and the exhaustive fallback) and keeps
@@ -97,15 +148,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_flow_lane8(SearchArgs a, FlowTa
     rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
     int subdir = 8;
     int start_row = 4, prune_pays = 1;  // (unused: the grouped kernel always searches exhaustively)
-    if (live) subdir = search_block<SUBPIXEL, false>(a, pair0 + (uint32_t)p, (uint32_t)blk,
-                                                     (pair0 + (uint32_t)p) * (uint32_t)nb + (uint32_t)blk, true, rec,
+    // (a live lane's record index (pair0 + p) * nb + blk is pair0 * nb + tid)
+    if (live) subdir = search_block<SUBPIXEL, false>(a, pair0 + (uint32_t)p, (uint32_t)blk, pair0 * (uint32_t)nb, true, rec,
                                                      start_row, prune_pays);
-    const bool ok = live && (uint32_t)rec.sad < (uint32_t)a.value_threshold;  // skipped = 0xFFFF
+    // (the lane's pair is derived again from an opaque copy of its id: nothing of it holds a register
+    //  during the search, which sits at the 128 VGPRs of four waves per SIMD)
+    uint32_t tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const bool live2 = (int)tid2 < np * nb;
+    const int p2 = live2 ? (int)fast_div(tid2, a.div_nb) : 0;
+    const bool ok = live2 && (uint32_t)rec.sad < (uint32_t)a.value_threshold;  // skipped = 0xFFFF
     const int hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
     const int hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
-    wave_vote2(s_votes, s_votes, p * 2 * n + 2 * rec.dx + hx + centre, p * 2 * n + n + 2 * rec.dy + hy + centre, ok);
+    wave_vote2(s_votes, s_votes, p2 * 2 * n + 2 * rec.dx + hx + centre, p2 * 2 * n + n + 2 * rec.dy + hy + centre, ok);
     __syncthreads();
-    if (tid < np) {
+    if ((int)tid2 < np) {
+        const int tid = (int)tid2;
         const uint32_t *hxp = s_votes + tid * 2 * n, *hyp = hxp + n;
         int sums[3] = {0, 0, 0};
         for (int k = 0; k < n; k++) {
@@ -162,13 +220,48 @@ int for_slices(const SearchArgs &a, F &&launch)
 
 }  // namespace
 
-int launch_search_lane8(const SearchArgs &a, void *stream)
+// Workgroup size of the flat kernels.  Large launches: 64, 128 and 256 threads measure the same (512 is
+// 4 % slower).  A launch of only a few generations of waves (configs[3]'s per-GPU share: 128 VGA pairs
+// are 2.3 generations) ends sooner with one-wave workgroups, whose slots free up wave by wave.
+#ifndef AOF_LANE8_SMALL_THREADS
+#define AOF_LANE8_SMALL_THREADS 64
+#endif
+static int flat_threads(int64_t items)
+{
+    return items < 6 * 256 * 1024 ? AOF_LANE8_SMALL_THREADS : kThreads;   // fewer than six generations of 256 CUs x 16 waves
+}
+
+bool lane8_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t capacity_pairs)
+{
+    const int n = 2 * (2 * a.hist_range + 1) + 1;
+    if (a.prune || !votes.base || n > 62 || votes.stride < (uint32_t)(2 + 2 * n)) return false;
+    if (a.grid.blocks() <= 64) return false;   // a wave covers at most two pairs
+    const int64_t per = kMaxItems / a.grid.blocks();   // pairs per launch slice
+    return (a.n_pairs < per ? a.n_pairs : per) <= capacity_pairs;
+}
+
+int launch_search_lane8(const SearchArgs &a, void *stream, const FlowTail *tail, const VoteMem *votes)
 {
     if (a.n_pairs == 0) return 0;
     if (a.subpixel && !a.subdirs) return (int)hipErrorInvalidValue;
-    return for_slices(a, [&](const SearchArgs &s, int64_t) {
+    return for_slices(a, [&](const SearchArgs &s, int64_t done) {
         const int64_t items = s.n_pairs * s.grid.blocks();
-        const int64_t chunks = (items + kThreads - 1) / kThreads;
+        if (tail && votes) {   // search + reduction in one launch
+            const int threads = flat_threads(items);
+            const int64_t wgs = (items + threads - 1) / threads;
+            const int64_t finalisers = (s.n_pairs + threads / 64 - 1) / (threads / 64);   // one wave per pair
+            FlowTail t = *tail;
+            t.flows += done;
+            if (t.pred) t.pred += done;
+            void (*fn)(SearchArgs, uint32_t, uint32_t, FlowTail, VoteMem);
+            if (s.sums) fn = s.subpixel ? k_flow_lane8_flat<true, true> : k_flow_lane8_flat<false, true>;
+            else fn = s.subpixel ? k_flow_lane8_flat<true, false> : k_flow_lane8_flat<false, false>;
+            hipLaunchKernelGGL(fn, dim3((uint32_t)(wgs + finalisers)), dim3(threads), 0,
+                               static_cast<hipStream_t>(stream), s, (uint32_t)items, (uint32_t)wgs, t, *votes);
+            return (int)hipGetLastError();
+        }
+        const int threads = s.prune ? kThreads : flat_threads(items);
+        const int64_t chunks = (items + threads - 1) / threads;
         // pruned search: consecutive chunks per workgroup so that all but the first inherit a start
         // row; fewer when the launch is small and needs the workgroups for parallelism
         int spw = 1;
@@ -178,7 +271,7 @@ int launch_search_lane8(const SearchArgs &a, void *stream)
         if (s.prune) fn = s.subpixel ? k_search_lane8_pruned<true> : k_search_lane8_pruned<false>;
         else if (s.sums) fn = s.subpixel ? k_search_lane8<true, true> : k_search_lane8<false, true>;
         else fn = s.subpixel ? k_search_lane8<true, false> : k_search_lane8<false, false>;
-        hipLaunchKernelGGL(fn, dim3((uint32_t)wgs), dim3(kThreads), 0, static_cast<hipStream_t>(stream), s,
+        hipLaunchKernelGGL(fn, dim3((uint32_t)wgs), dim3(threads), 0, static_cast<hipStream_t>(stream), s,
                            (uint32_t)items, (uint32_t)wgs, spw);
         return (int)hipGetLastError();
     });

@@ -360,8 +360,15 @@ def main():
     ap.add_argument("--coarse", default="auto", choices=["auto", "split"],
                     help="two-level workloads: how the coarse passes run -- auto (the fused kernel k_coarse where the "
                          "geometry allows) or split (K1 / level-1 search / K3 as separate kernels)")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture one step's launch sequence into a hipGraph and replay it per step")
+    ap.add_argument("--reduce", default="separate", choices=["separate", "fused"],
+                    help="separate: K3 behind the search (default); fused: the 8x8 search kernel reduces in its "
+                         "own launch (votes through agent-scope atomics, finaliser waves behind the search)")
+    ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help="replay one step's launch sequence as a hipGraph: auto (default) = for N > 1 and for "
+                         "launch-bound steps (fewer than 2 Mi blocks per step), on, off")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent batches in flight: step i runs on HIP stream i %% S with its own context, "
+                         "record buffers and workspace (default 1)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="rehearse the N>1 control flow without a GPU: rendezvous, shard, gather a batch of "
                          "placeholder flow records over gloo, print one line and leave (CPU test of the launch path)")
@@ -406,17 +413,21 @@ def main():
     over = dict(over)
     p = aof.px4flow_params(W, H, **over) if over.pop("_px4flow", 0) else aof.default_params(W, H, **over)
     eng = aof.FlowEngine(p, dev_index)
-    if args.search == "pruned":
-        eng.set_search_mode(aof.SEARCH_PRUNED)
-    elif args.search == "strips":
-        eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
-    elif args.search == "pruned_strips":
-        eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
-    if args.force_generic:
-        eng.force_generic(True)
-    eng.set_pipeline(args.pipeline)
-    if args.coarse != "auto":
-        eng.set_split_coarse(True)
+
+    def configure(e):
+        if args.search == "pruned":
+            e.set_search_mode(aof.SEARCH_PRUNED)
+        elif args.search == "strips":
+            e.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
+        elif args.search == "pruned_strips":
+            e.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
+        if args.force_generic:
+            e.force_generic(True)
+        e.set_pipeline(args.pipeline)
+        e.set_reduce_fusion(args.reduce == "fused")
+        if args.coarse != "auto":
+            e.set_split_coarse(True)
+    configure(eng)
     if args.scaling == "strong":
         sb, se = batch.shard_range(args.pairs, rank, world)
         n = se - sb
@@ -434,38 +445,71 @@ def main():
         cur = (cur.to(torch.int16) + nz).clamp_(0, 255).to(torch.uint8)
         del nz
     nb = eng.nblocks(0)
-    blocks = torch.empty((n, nb), dtype=torch.int32, device=device)
-    flows2 = [torch.empty((n, 16), dtype=torch.uint8, device=device) for _ in range(2)]
-    flows = flows2[0]
     L = aof.workspace_layout(p, n)
-    ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=device)
 
-    state = {"i": 0, "pending": None, "gathered": None}
-    graphs = None
-    if args.graph:
-        graphs = []
-        for f in flows2:   # one graph per flow buffer (the gather of step i overlaps step i+1)
-            eng.flow_batch(prev, cur, blocks=blocks, flows=f, workspace=ws)
-            torch.cuda.synchronize(device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                eng.flow_batch(prev, cur, blocks=blocks, flows=f, workspace=ws)
-            graphs.append(g)
+    # A LANE = one context with its own stream, record buffers and workspace; the frames are shared
+    # (read-only).  --streams 1 (default): one lane on torch's current stream, whose two flow buffers
+    # alternate so that the gather of step i overlaps step i+1.  --streams S: step i runs on lane i % S,
+    # so that the launch gaps and the low-occupancy reduction of one batch are covered by the search of
+    # the next one (independent batches in flight on separate HIP streams).
+    class Lane:
+        pass
+    lanes = []
+    for li in range(max(1, args.streams)):
+        ln = Lane()
+        ln.eng = eng if li == 0 else aof.FlowEngine(p, dev_index)
+        if li:
+            configure(ln.eng)
+        ln.stream = torch.cuda.current_stream(device) if args.streams <= 1 else torch.cuda.Stream(device)
+        ln.blocks = torch.empty((n, nb), dtype=torch.int32, device=device)
+        ln.sub = torch.empty((n, nb), dtype=torch.uint8, device=device) if p.subpixel else None
+        ln.ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=device)
+        ln.flows = [torch.empty((n, 16), dtype=torch.uint8, device=device) for _ in range(2 if args.streams <= 1 else 1)]
+        ln.enqueue = [ln.eng.bind_batch(prev, cur, ln.blocks, f, ln.ws, subdirs=ln.sub,
+                                        stream=ln.stream.cuda_stream if args.streams > 1 else None)
+                      for f in ln.flows]   # one ctypes call per step
+        ln.graphs = None
+        ln.i = 0
+        lanes.append(ln)
+    blocks, flows2 = lanes[0].blocks, lanes[0].flows
+    ws = lanes[0].ws
+    state = {"i": 0, "pending": None, "gathered": None, "last": (lanes[0], 0)}
+    multi = len(lanes) > 1
+    use_graph = args.graph == "on" or (args.graph == "auto" and (world > 1 or n * nb < (1 << 21)))
+    if use_graph:   # a short step is launch-bound: replay it as one hipGraph
+        for ln in lanes:
+            ln.graphs = []
+            for e in ln.enqueue:
+                e()
+                torch.cuda.synchronize(device)
+                g = torch.cuda.CUDAGraph()
+                if multi:
+                    with torch.cuda.graph(g, stream=ln.stream):
+                        e()
+                else:   # (captured on torch's side stream, replayed on the current one)
+                    with torch.cuda.graph(g):
+                        e()
+                ln.graphs.append(g)
 
     def step():
-        # Two flow buffers alternate so that the gather of step i (the only exchange of the
-        # batched mode: 16 B per pair, every rank gets all flows) crosses xGMI on RCCL's
-        # stream while step i+1's search is already enqueued.
-        f = flows2[state["i"] & 1]
-        if graphs is not None and not eng_profiling["on"]:
-            graphs[state["i"] & 1].replay()
-        else:
-            eng.flow_batch(prev, cur, blocks=blocks, flows=f, workspace=ws)
+        ln = lanes[state["i"] % len(lanes)]
+        k = ln.i % len(ln.flows)
+        ln.i += 1
         state["i"] += 1
+        state["last"] = (ln, k)
+        if ln.graphs is not None and not eng_profiling["on"]:
+            if multi:
+                torch.cuda.set_stream(ln.stream)
+            ln.graphs[k].replay()
+        else:
+            ln.enqueue[k]()
         if world == 1:
             return
+        if multi:
+            torch.cuda.set_stream(ln.stream)
         if state["pending"] is not None:
             state["gathered"] = state["pending"].wait()
+        f = ln.flows[k]
         src = f.cpu() if args.backend == "gloo" else f  # gloo (rehearsal) gathers host copies
         state["pending"] = batch.gather_flows_async(src, world * n)
 
@@ -489,9 +533,6 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # HIP events around the dominant kernel (K2, level 0) of every launch, on the launch stream;
-    # the other kernels are timed in a few extra steps after the timed region, because every
-    # event pair costs the stream a few microseconds of serialisation
     # Untimed settling phase before the W warm-up steps: the device's clocks take tens of
     # milliseconds of sustained load to settle (measured: K2 0.251 ms in a cold 20-step run,
     # 0.227 ms after 150 ms of load), and W is often only a handful of steps.  A fixed number of
@@ -502,15 +543,15 @@ def main():
             drain()
             torch.cuda.synchronize(device)
     fence()
+    # HIP events around the dominant kernel (K2, level 0) on the launch stream.  Steps of a millisecond
+    # or so carry them inside the timed region; every event pair costs the stream a few microseconds of
+    # serialisation, so short steps (and replayed graphs, pipelined sub-batches, several lanes) are timed
+    # without events and K2 is measured in a second pass of the same K steps on lane 0 right after it.
     eng.set_profiling(True, kernels=[aof.K_SEARCH])
-    step()
+    lanes[0].enqueue[0]()
     fence()
     lps = max(1, len(eng.profile_ms(aof.K_SEARCH)))   # K2 launches per step (pipelined sub-batches)
-    # One K2 launch per step: its events are recorded inside the timed region.  A pipelined step
-    # has one K2 launch per sub-batch on a stream that other kernels overlap; bracketing each
-    # with events would serialise what the pipeline overlaps, so the timed region then runs
-    # without events and K2 is timed in a second pass of the same K steps right after it.
-    events_in_timed_region = lps == 1 and not args.graph
+    events_in_timed_region = lps == 1 and not use_graph and not multi and n * nb >= (1 << 21)
     eng.set_profiling(events_in_timed_region, kernels=[aof.K_SEARCH])
     for _ in range(args.warmup):
         step()
@@ -520,10 +561,26 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    # Per-step times for the median: a further pass of the same K steps with one event behind every step
+    # (outside the timed region, so that `value` is not taxed with the event records).
+    marks = []
+    for _ in range(args.steps):
+        step()
+        ln, _k = state["last"]
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(ln.stream)
+        marks.append((ln, ev))
+    fence()
+    per_step_ms = []
+    stride = len(lanes)
+    for j in range(stride, len(marks)):   # lane-local interval = `stride` steps of the job
+        per_step_ms.append(marks[j - stride][1].elapsed_time(marks[j][1]) / stride)
+    if multi:
+        torch.cuda.set_stream(torch.cuda.default_stream(device))
     if not events_in_timed_region:
         eng.set_profiling(True, kernels=[aof.K_SEARCH])
         for _ in range(args.steps):
-            step()
+            lanes[0].enqueue[0]()
         fence()
     eng.set_profiling(False)
     if world > 1:
@@ -538,7 +595,7 @@ def main():
     k2_ms = float(np.sum(k2)) / (len(k2) // lps) if k2 else float("nan")
     eng.set_profiling(True)          # all kernels, outside the timed region
     for _ in range(5):
-        step()
+        lanes[0].enqueue[0]()
     fence()
     eng.set_profiling(False)
     per_kernel = {}
@@ -547,6 +604,9 @@ def main():
         v = eng.profile_ms(kid)
         if v:   # per step: the sum over the step's sub-batch launches
             per_kernel[name] = round(float(np.sum(v)) / 5, 5)
+    if "pyramid" in per_kernel and "search_l1" not in per_kernel and p.pyramid_levels == 2:
+        # the AOF_K_PYRAMID bracket timed k_coarse: sums + pyramid + level-1 search + level-1 reduction
+        per_kernel["coarse_fused"] = per_kernel.pop("pyramid")
     per_kernel["search"] = round(k2_ms, 5)  # the timed region's own measurement
     alg_bytes = aof.algorithmic_bytes(p)
     achieved = alg_bytes * n / (k2_ms * 1e-3) / 1e9
@@ -563,10 +623,17 @@ def main():
         "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle_steps,
         "ms_per_step": round(step_ms, 4),
+        "timed_region_ms": round(elapsed * 1e3, 3),
+        # median over per-step HIP-event intervals of a further pass of the same K steps
+        "ms_per_step_median": round(float(np.median(per_step_ms)), 5) if per_step_ms else None,
+        "value_median": round(world * n / (float(np.median(per_step_ms)) * 1e-3), 1) if per_step_ms else None,
+        "ms_per_step_p10_p90": [round(float(np.percentile(per_step_ms, 10)), 5),
+                                round(float(np.percentile(per_step_ms, 90)), 5)] if per_step_ms else None,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_gpu": n, "global_pairs": world * n,
-                   "search_kernel": eng.variant, "search": args.search, "coarse": args.coarse, "k2_launches_per_step": lps, "noise_lsb": args.noise, "exposure_step": brightness, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
+                   "search_kernel": eng.variant, "search": args.search, "coarse": args.coarse, "reduce": args.reduce,
+                   "streams": len(lanes), "graph_replay": bool(use_graph), "k2_launches_per_step": lps, "noise_lsb": args.noise, "exposure_step": brightness, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -597,11 +664,11 @@ def main():
         eng.set_search_mode(aof.SEARCH_PRUNED)
         eng.set_profiling(True)
         for _ in range(2):
-            eng.flow_batch(prev, cur, blocks=blocks, flows=flows2[0], workspace=ws)
+            lanes[0].enqueue[0]()
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            eng.flow_batch(prev, cur, blocks=blocks, flows=flows2[0], workspace=ws)
+            lanes[0].enqueue[0]()
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t1
         pk2 = eng.profile_ms(aof.K_SEARCH)
@@ -615,19 +682,20 @@ def main():
             "records_identical_to_exhaustive": bool(torch.equal(ref_blocks, blocks)),
             "note": "opt-in AOF_SEARCH_PRUNED (partial-distortion elimination): bit-identical records, "
                     "rate depends on the images; not the headline"}
-        state["i"] = 1  # flows2[0] holds the latest records
+        state["last"] = (lanes[0], 0)  # its first flow buffer holds the latest records
 
     # ---- parity on a sample + CPU baseline (rank 0, N=1 only) ----
     if rank == 0:
         from oracle import pyoracle as orc
         po = orc.params_from(p)
-        gb, gf = aof.blocks_view(blocks[:4]), aof.flows_view(flows2[(state["i"] - 1) & 1][:4])
+        ln, k = state["last"]
+        flows = ln.flows[k]
+        gb, gf = aof.blocks_view(ln.blocks[:4]), aof.flows_view(flows[:4])
         hp, hc = prev[:4].cpu().numpy(), cur[:4].cpu().numpy()
         ok = True
         for i in range(4):
             ref = orc.flow_pair(po, hp[i], hc[i])
             ok &= gb[i].tobytes() == ref["blocks"].tobytes() and gf[i].tobytes() == ref["flow"].tobytes()
-        flows = flows2[(state["i"] - 1) & 1]
         fl = aof.flows_view(flows)
         known = bool(np.array_equal(fl["flow_x"], shifts[:, 0].astype(np.float32)) and
                      np.array_equal(fl["flow_y"], shifts[:, 1].astype(np.float32))) if not args.noise else None
@@ -652,8 +720,21 @@ def main():
                     done += m
             finally:
                 orc.set_fast_sad(False)
+            # the same oracle on ONE thread, a few seconds
+            one_done, one_spent = 0, 0.0
+            orc.set_fast_sad(simd)
+            try:
+                while one_spent < min(3.0, args.cpu_seconds):
+                    t1 = time.perf_counter()
+                    orc.flow_batch(po, hp[:4], hc[:4], threads=1)
+                    one_spent += time.perf_counter() - t1
+                    one_done += 4
+            finally:
+                orc.set_fast_sad(False)
             out["cpu_baseline"] = {"value": round(done / spent, 2), "unit": "frame-pairs/s",
                                    "cores": int(used), "kind": "port",
+                                   "single_thread": {"value": round(one_done / one_spent, 2), "unit": "frame-pairs/s",
+                                                     "cores": 1, "sample": f"{one_done} pairs, {one_spent:.1f} s"},
                                    "sample": f"{done} pairs ({m} distinct) of the same workload, this repo's "
                                              f"C oracle (-O2, SAD via {'SSE2 psadbw' if simd else 'the byte loop'}), "
                                              f"OpenMP over pairs, {spent:.1f} s"}

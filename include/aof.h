@@ -166,6 +166,17 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
  * keeps small batches (see aof_flow_batch_device) on the separate kernels as well. */
 int aof_set_split_coarse(aof_ctx *ctx, int on);
 
+/* 8x8 tiles on grids of more than 256 blocks (C2, C3): the search kernel also reduces -- every wave adds
+ * its votes to the pair's record in the CONTEXT's vote memory with integer atomics and the last wave
+ * of a pair writes its aof_flow -- so no K3 launch follows (at 128 VGA pairs per call, configs[3]'s
+ * per-GPU share, K3 and its launch gap were a quarter of the step).  Integer adds commute: the records
+ * are bit-identical to the separate K3's.  Because the vote memory belongs to the context, calls on
+ * ONE context must not overlap on the device: eager calls on different streams are ordered behind each
+ * other by the library; captured graphs that contain calls on a context must not be replayed
+ * concurrently with each other or with eager calls on it.  on = 0 launches K3 as a separate kernel
+ * instead (tests compare the two); 1 = default. */
+int aof_set_reduce_fusion(aof_ctx *ctx, int on);
+
 /* Two-level configurations cut a large batch into sub-batches and run the HBM-bound coarse
  * passes (pixel sums + 2x2 pyramid, level-1 search and reduce) of sub-batch i+1 on an internal
  * second stream under the VALU-bound level-0 search of sub-batch i; everything still joins the

@@ -420,6 +420,104 @@ def test_fused_coarse_kernel_walks_many_pairs_per_workgroup(aof, orc, synth, gpu
         assert outs[0][k] == outs[1][k], f"{name} differ between the fused and the split coarse passes"
 
 
+def test_fused_coarse_kernel_at_vga_beyond_the_first_generation(aof, orc, synth, gpu_device):
+    """k_coarse at its BASELINE size (configs[2]: 640x480, 150 KB of level-1 frames in LDS) and past the
+    first generation of workgroups: 600 VGA pairs on 256 CUs, which engages the three-group start-up
+    stagger (from 512 pairs), the row prefetch across pairs and the two alternating histogram sets.
+    Every pair byte-for-byte against the split kernels (records, flows, predictors, pixel sums), a
+    sample that straddles the generation boundaries against the oracle."""
+    import torch
+    W, H = 640, 480
+    p = aof.default_params(W, H, pyramid_levels=2, mean_subtract=1)
+    n, distinct = 600, 24
+    hp, hc, _ = synth.make_batch(W, H, distinct, 9, 9300, noise=3, brightness=9)
+    hp[5, : H // 2] = 9                          # flat upper half: gated blocks at both levels
+    hc[5, : H // 2] = 9
+    hc[6] = np.minimum(hc[6].astype(np.int32) * 2, 255).astype(np.uint8)   # the clamp of the equalisation bites
+    idx = (np.arange(n) * 7) % distinct
+    jdx = (idx + (np.arange(n) // 200)) % distinct   # pairs 200.. are mismatched frames: no common motion
+    prev = torch.from_numpy(hp[idx]).to(gpu_device)
+    cur = torch.from_numpy(hc[jdx]).to(gpu_device)
+    outs = []
+    for split in (False, True):
+        eng = aof.FlowEngine(p, 0)
+        eng.set_split_coarse(split)
+        blocks, flows, ws = eng.flow_batch(prev, cur)
+        torch.cuda.synchronize()
+        L = aof.workspace_layout(p, n)
+        nb1 = eng.nblocks(1)
+        outs.append((blocks.cpu().numpy().tobytes(), flows.cpu().numpy().tobytes(),
+                     ws[L.l1_blocks:L.l1_blocks + 4 * nb1 * n].cpu().numpy().tobytes(),
+                     ws[L.l1_flows:L.l1_flows + 16 * n].cpu().numpy().tobytes(),
+                     ws[L.sums:L.sums + 16 * n].cpu().numpy().tobytes()))
+        if not split:
+            sample = [0, 5, 6, 199, 200, 255, 256, 257, 511, 512, 513, 599]
+            check_against_oracle(aof, orc, p, hp[idx[sample]], hc[jdx[sample]],
+                                 dict(blocks=aof.blocks_view(blocks)[sample], flows=aof.flows_view(flows)[sample]))
+        del blocks, flows, ws
+        eng.close()
+    for k, name in enumerate(("records", "flows", "level-1 records", "predictors", "sums")):
+        assert outs[0][k] == outs[1][k], f"{name} differ between the fused and the split coarse passes"
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(subpixel=1), dict(pyramid_levels=2, mean_subtract=1),
+                                dict(hist_filter=0, min_valid=3), dict(pyramid_levels=2, subpixel=1)])
+@pytest.mark.parametrize("shape", [(640, 480), (200, 150)])
+def test_reduction_inside_the_search_launch_equals_k3(aof, orc, synth, gpu_device, shape, kw):
+    """The flat lane8 search reduces in its own launch (votes through agent-scope atomics into the
+    context's vote memory, the last wave of a pair writes its flow record): flow records and block
+    records byte-for-byte against the separate K3 launch and a sample against the oracle -- on common
+    motions (two adds per wave), on mismatched frames (votes all over the histogram), gated and
+    saturated pairs; launched repeatedly (the vote memory must be zero again after every launch), on
+    alternating streams, and replayed from a captured graph."""
+    import torch
+    W, H = shape
+    p = aof.default_params(W, H, **kw)
+    n, distinct = 131, 12
+    reach = 9 if kw.get("pyramid_levels") == 2 else 4
+    hp, hc, _ = synth.make_batch(W, H, distinct, reach, 9400 + W, noise=3, brightness=7 if kw.get("mean_subtract") else 0)
+    hp[3, : H // 2] = 9
+    hc[3, : H // 2] = 9
+    hp[4] = 0                                    # black previous frame: everything gated, no votes at all
+    idx = (np.arange(n) * 5) % distinct
+    jdx = (idx + (np.arange(n) // 60)) % distinct   # pairs 60.. compare unrelated frames
+    prev = torch.from_numpy(hp[idx]).to(gpu_device)
+    cur = torch.from_numpy(hc[jdx]).to(gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    assert eng.variant == "lane8"
+    eng.set_reduce_fusion(False)
+    b_ref, f_ref, _ = eng.flow_batch(prev, cur)
+    torch.cuda.synchronize()
+    sample = [0, 3, 4, 59, 60, 61, 130]
+    check_against_oracle(aof, orc, p, hp[idx[sample]], hc[jdx[sample]],
+                         dict(blocks=aof.blocks_view(b_ref)[sample], flows=aof.flows_view(f_ref)[sample]))
+    eng.set_reduce_fusion(True)
+    side = torch.cuda.Stream(gpu_device)
+    for rep in range(4):
+        blocks, flows = torch.zeros_like(b_ref), torch.zeros_like(f_ref)
+        if rep & 1:   # another stream than the previous launch: the library orders the two
+            with torch.cuda.stream(side):
+                eng.flow_batch(prev, cur, blocks=blocks, flows=flows)
+        else:
+            eng.flow_batch(prev, cur, blocks=blocks, flows=flows)
+        torch.cuda.synchronize()
+        assert torch.equal(blocks, b_ref), f"launch {rep}: block records differ"
+        assert torch.equal(flows, f_ref), f"launch {rep}: flow records differ"
+    blocks, flows = torch.zeros_like(b_ref), torch.zeros_like(f_ref)
+    ws = torch.zeros(aof.workspace_layout(p, n).total_bytes, dtype=torch.uint8, device=gpu_device)
+    eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+    for rep in range(3):
+        flows.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(flows, f_ref) and torch.equal(blocks, b_ref), f"graph replay {rep}"
+    eng.close()
+
+
 # ---- shapes, options and edge cases ---------------------------------------------
 
 SHAPES = [

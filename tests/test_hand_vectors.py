@@ -99,6 +99,70 @@ def case_two_levels_reach_six_pixels():
     return prev, cur, params, blocks, flow
 
 
+def case_tile16_uniform_shift():
+    """64x64, 16x16 tiles, S=8 (BASELINE configs[4]'s kernel class): dense grid origin 8, step 16,
+    nx = ny = floor((64 - 16)/16) = 3 -> 9 blocks at x,y in {8, 24, 40}.
+    cur[y][x] = prev[y-5][x+7] wherever both exist (y >= 5, x <= 56): the tile of prev at (i, j)
+    reappears in cur at (i-7, j+5) -- x = 1..49 and y = 13..60 for the nine tiles, all inside the
+    defined region and inside every block's window [i-8, i+23] x [j-8, j+23] -- so every record is
+    (dx, dy, sad) = (-7, +5, 0).  R = S = 8, centre 2R+1 = 17: x bin = -14 + 17 = 3, y bin =
+    10 + 17 = 27, nine votes each, lone peaks -> flow (-7.0, 5.0); count 9 > min_valid 0;
+    quality = 9*255/9 = 255."""
+    prev = texture(64, 64)
+    cur = np.full((64, 64), 3, np.uint8)
+    cur[5:64, 0:57] = prev[0:59, 7:64]
+    params = dict(width=64, height=64, tile=16, search=8, min_valid=0)
+    flow = dict(flow_x=-7.0, flow_y=5.0, count=9, quality=255, flags=1)
+    return prev, cur, params, [(-7, 5, 0)] * 9, flow
+
+
+def case_tile16_two_motions_and_a_gated_block():
+    """96x64, 16x16 tiles, S=8: 5x3 blocks at x in {8, 24, 40, 56, 72}, y in {8, 24, 40}.  Block columns
+    8..55 (three columns) move by dx = -3, columns 56..87 (two columns) by dx = -2, dy = 0 everywhere
+    (columns of cur: 5..52 <- prev 8..55, 54..85 <- prev 56..87; the destination ranges do not overlap
+    and every tile lands inside its own window).  Block (x=24, y=24) of prev is painted flat: 4x4
+    gradient sum 0 < 30 -> gated (sad 0xFFFF, no vote).
+    Votes x: bin 2*(-3)+17 = 11 eight times (nine tiles minus the gated one), bin 2*(-2)+17 = 13 six
+    times; y: bin 17 fourteen times.  Peak x = bin 11 (8 votes); window 9..13: sum k*h = 11*8 + 13*6 =
+    166, sum h = 14 -> flow_x = (166/14 - 17)/2 in float32 arithmetic; flow_y = 0; count 14;
+    quality = floor(14*255/15) = 238."""
+    prev = texture(64, 96)
+    prev[24:40, 24:40] = 77
+    cur = np.full((64, 96), 200, np.uint8)
+    cur[:, 5:53] = prev[:, 8:56]
+    cur[:, 54:86] = prev[:, 56:88]
+    params = dict(width=96, height=64, tile=16, search=8, min_valid=0)
+    row = [(-3, 0, 0)] * 3 + [(-2, 0, 0)] * 2
+    blocks = row + [(-3, 0, 0), (0, 0, 0xFFFF), (-3, 0, 0), (-2, 0, 0), (-2, 0, 0)] + row
+    fx = (np.float32(166) / np.float32(14) - np.float32(17)) / np.float32(2)
+    flow = dict(flow_x=float(fx), flow_y=0.0, count=14, quality=238, flags=1)
+    return prev, cur, params, blocks, flow
+
+
+def case_tile16_two_levels_reach_twelve_pixels():
+    """96x96, 16x16 tiles, S=8, two levels, cur[y][x] = prev[y+6][x-12]: a shift of (+12, -6), beyond the
+    +-8 of one level.  An even shift commutes with the 2x2 box filter: cur1[y][x] = prev1[y+3][x-6], so
+    the four level-1 blocks (48x48, origin 8, step 16: x,y in {8, 24}) match at (6, -3) with SAD 0
+    (tiles land at x = 14..45, y = 5..36: inside the defined region x >= 6, y < 45 and the windows):
+    level-1 flow (6, -3), predictor (12, -6) level-0 pixels, valid.
+    Level 0: 5x5 blocks at 8, 24, .., 72.  Under the predictor the window of a block at (i, j) spans
+    x = i+4 .. i+35, y = j-14 .. j+17: inside the frame for i <= 60 and j >= 14, i.e. columns 8..56 and
+    rows 24..72 -- 16 blocks, each matching at the window's centre: (12, -6, 0); the other nine are
+    skipped (0, 0, 0xFFFF).  R = 3S+1 = 25, centre 51: x bin 24+51 = 75, y bin -12+51 = 39, 16 votes
+    each, lone peaks -> flow (12.0, -6.0); count 16; quality = floor(16*255/25) = 163; flags = flow
+    valid | predictor valid = 3."""
+    prev = texture(96, 96)
+    cur = np.full((96, 96), 3, np.uint8)
+    cur[0:90, 12:96] = prev[6:96, 0:84]
+    params = dict(width=96, height=96, tile=16, search=8, min_valid=0, pyramid_levels=2)
+    blocks = []
+    for j in (8, 24, 40, 56, 72):
+        for i in (8, 24, 40, 56, 72):
+            blocks.append((12, -6, 0) if i <= 60 and j >= 14 else (0, 0, 0xFFFF))
+    flow = dict(flow_x=12.0, flow_y=-6.0, count=16, quality=163, flags=3)
+    return prev, cur, params, blocks, flow
+
+
 def case_half_pixel():
     """40x40 with half-pixel refinement (dense grid at origin S+1 = 5, step 8: 3x3 blocks).
     prev[y][x] = (cur[y][x] + cur[y][x+1]) >> 1: prev is cur sampled half a pixel to the right.  Whatever
@@ -144,6 +208,9 @@ def all_cases():
     yield p, c, starved[0], blocks, starved[1]
     yield case_exposure_step()
     yield case_two_levels_reach_six_pixels()
+    yield case_tile16_uniform_shift()
+    yield case_tile16_two_motions_and_a_gated_block()
+    yield case_tile16_two_levels_reach_twelve_pixels()
 
 
 def test_oracle_reproduces_the_hand_vectors(orc):
@@ -177,10 +244,15 @@ def test_hip_path_reproduces_the_hand_vectors(aof, gpu_device):
     for prev, cur, params, blocks, flow in all_cases():
         w, h = params["width"], params["height"]
         p = aof.default_params(w, h, **{k: v for k, v in params.items() if k not in ("width", "height")})
-        for generic, split in ((False, False), (True, False), (False, True)):   # default / generic / separate kernels
+        # default / generic / separate kernels / exact pruned search (16x16: k_search_tile16<PRUNE>)
+        for generic, split, mode in ((False, False, aof.SEARCH_EXHAUSTIVE), (True, False, aof.SEARCH_EXHAUSTIVE),
+                                     (False, True, aof.SEARCH_EXHAUSTIVE), (False, False, aof.SEARCH_PRUNED)):
             eng = aof.FlowEngine(p, 0)
             eng.force_generic(generic)
             eng.set_split_coarse(split)
+            eng.set_search_mode(mode)
+            if params.get("tile") == 16 and not generic:
+                assert eng.variant == "tile16_lds"
             got_blocks, _, got_flow = eng.flow_pair_host(prev, cur)
             check(got_blocks, got_flow, blocks, flow)
             eng.close()
