@@ -360,15 +360,18 @@ def main():
     ap.add_argument("--coarse", default="auto", choices=["auto", "split"],
                     help="two-level workloads: how the coarse passes run -- auto (the fused kernel k_coarse where the "
                          "geometry allows) or split (K1 / level-1 search / K3 as separate kernels)")
-    ap.add_argument("--reduce", default="separate", choices=["separate", "fused"],
-                    help="separate: K3 behind the search (default); fused: the 8x8 search kernel reduces in its "
-                         "own launch (votes through agent-scope atomics, finaliser waves behind the search)")
+    ap.add_argument("--reduce", default="auto", choices=["auto", "separate", "fused"],
+                    help="separate: K3 behind the search; fused: the 8x8 search kernel reduces in its own launch "
+                         "(votes through agent-scope atomics, finaliser waves behind the search); auto (default): "
+                         "fused when several batches are in flight and the launch has at most 512 pairs -- the only "
+                         "place where it measured faster (one kernel per batch leaves no gap for the other lane)")
     ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="replay one step's launch sequence as a hipGraph: auto (default) = for N > 1 and for "
                          "launch-bound steps (fewer than 2 Mi blocks per step), on, off")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=0,
                     help="independent batches in flight: step i runs on HIP stream i %% S with its own context, "
-                         "record buffers and workspace (default 1)")
+                         "record buffers and workspace.  0 (default) = automatic: 2 when a step is launch-bound "
+                         "(fewer than 2 Mi blocks: configs[3]'s 128 pairs per GPU), else 1")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="rehearse the N>1 control flow without a GPU: rendezvous, shard, gather a batch of "
                          "placeholder flow records over gloo, print one line and leave (CPU test of the launch path)")
@@ -424,10 +427,9 @@ def main():
         if args.force_generic:
             e.force_generic(True)
         e.set_pipeline(args.pipeline)
-        e.set_reduce_fusion(args.reduce == "fused")
+        e.set_reduce_fusion(reduce_mode == "fused")
         if args.coarse != "auto":
             e.set_split_coarse(True)
-    configure(eng)
     if args.scaling == "strong":
         sb, se = batch.shard_range(args.pairs, rank, world)
         n = se - sb
@@ -435,6 +437,12 @@ def main():
             sys.exit("--scaling strong needs --pairs divisible by the number of GPUs")
     else:
         n = args.pairs
+    if args.streams <= 0:
+        args.streams = 2 if n * eng.nblocks(0) < (1 << 21) else 1
+    reduce_mode = args.reduce
+    if reduce_mode == "auto":
+        reduce_mode = "fused" if args.streams > 1 and n <= 512 else "separate"
+    configure(eng)
     brightness = args.brightness if args.brightness is not None else (9 if p.mean_subtract else 0)
     prev, cur, shifts = make_batch_gpu(W, H, n, reach, 0xA0F + 7919 * rank, device,
                                        brightness=brightness)
@@ -632,7 +640,7 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_gpu": n, "global_pairs": world * n,
-                   "search_kernel": eng.variant, "search": args.search, "coarse": args.coarse, "reduce": args.reduce,
+                   "search_kernel": eng.variant, "search": args.search, "coarse": args.coarse, "reduce": reduce_mode,
                    "streams": len(lanes), "graph_replay": bool(use_graph), "k2_launches_per_step": lps, "noise_lsb": args.noise, "exposure_step": brightness, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

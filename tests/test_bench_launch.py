@@ -30,6 +30,14 @@ def test_plain_invocation_spawns_two_ranks(scaling, pairs, total):
                  "gathered_in_pair_order_on_every_rank": True}
 
 
+def test_eight_ranks_rehearse_configs3_on_cpu():
+    """BASELINE configs[3] as the driver would start it: 1 024 pairs sharded over EIGHT ranks, 128 each,
+    the records gathered in pair order on every rank (gloo, no GPU)."""
+    j = run_bench("--gpus", "8", "--rendezvous-only", "--scaling", "strong", "--pairs", "1024")
+    assert j == {"rendezvous_only": True, "n_ranks": 8, "global_pairs": 1024, "scaling": "strong",
+                 "gathered_in_pair_order_on_every_rank": True}
+
+
 def test_single_rank_needs_no_launcher():
     j = run_bench("--rendezvous-only", "--pairs", "3")
     assert j["n_ranks"] == 1 and j["global_pairs"] == 3 and j["gathered_in_pair_order_on_every_rank"]
@@ -46,3 +54,16 @@ def test_plain_two_rank_bench_line_on_one_gpu():
     k = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--settle-steps", "3",
                   "--pairs", "16", "--scaling", "strong", "--cpu-seconds", "0")
     assert k["scaling"] == "strong" and k["config"]["global_pairs"] == 16 and k["config"]["pairs_per_gpu"] == 8
+
+
+@pytest.mark.gpu
+def test_four_ranks_with_two_batches_in_flight_on_one_gpu():
+    """configs[3]'s per-GPU share as the strong-scaling line runs it: 128 VGA pairs per rank, two batches
+    in flight per rank (bench lanes on two HIP streams), the reduction inside the search launch, the
+    step replayed as a hipGraph -- four ranks sharing the one GPU of the box, gloo for the gather."""
+    j = run_bench("--gpus", "4", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--settle-steps", "4",
+                  "--pairs", "512", "--scaling", "strong", "--cpu-seconds", "0")
+    c = j["config"]
+    assert j["n_gpus"] == 4 and c["global_pairs"] == 512 and c["pairs_per_gpu"] == 128
+    assert c["streams"] == 2 and c["reduce"] == "fused" and c["graph_replay"]
+    assert j["value"] > 0 and j["parity"]["oracle_pairs_bit_exact"] and j["parity"]["all_pairs_return_known_shift"]
