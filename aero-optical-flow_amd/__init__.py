@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOF_LIB") or os.path.join(_HERE, "csrc", "libaof.so")
 
 GRID_DENSE, GRID_PX4FLOW = 0, 1
-SEARCH_EXHAUSTIVE, SEARCH_PRUNED, SEARCH_EXHAUSTIVE_STRIPS, SEARCH_PRUNED_STRIPS = 0, 1, 2, 3
+SEARCH_EXHAUSTIVE, SEARCH_PRUNED = 0, 1
 SAD_SKIPPED = 0xFFFF
 FLAG_FLOW_VALID, FLAG_PRED_VALID = 1, 2
 K_PYRAMID, K_SEARCH_L1, K_REDUCE_L1, K_SEARCH, K_REDUCE = range(5)
@@ -98,7 +98,6 @@ def _load():
         "aof_search_variant": (C.c_char_p, [VP]),
         "aof_set_force_generic": (C.c_int, [VP, C.c_int]),
         "aof_set_search_mode": (C.c_int, [VP, C.c_int]),
-        "aof_set_pipeline": (C.c_int, [VP, I64]),
         "aof_set_split_coarse": (C.c_int, [VP, C.c_int]),
         "aof_set_reduce_fusion": (C.c_int, [VP, C.c_int]),
         "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
@@ -256,8 +255,7 @@ class FlowEngine:
         self._check(lib.aof_set_force_generic(self._ctx, int(on)))
 
     def set_search_mode(self, mode):
-        """SEARCH_EXHAUSTIVE (default), SEARCH_PRUNED (exact, data-dependent rate) or
-        SEARCH_EXHAUSTIVE_STRIPS (exhaustive search in the LDS-strip kernel)."""
+        """SEARCH_EXHAUSTIVE (default) or SEARCH_PRUNED (exact, data-dependent rate)."""
         self._check(lib.aof_set_search_mode(self._ctx, int(mode)))
 
     def set_split_coarse(self, on=True):
@@ -270,12 +268,6 @@ class FlowEngine:
         if not hasattr(lib, "aof_set_reduce_fusion"):
             return   # (AOF_LIB pointing at an older build)
         self._check(lib.aof_set_reduce_fusion(self._ctx, int(on)))
-
-    def set_pipeline(self, sub_pairs):
-        """Two-level batches: pairs per pipelined sub-batch (0 = off, < 0 = automatic, the default)."""
-        if int(sub_pairs) == 0 and not hasattr(lib, "aof_set_pipeline"):
-            return   # (AOF_LIB pointing at an older build)
-        self._check(lib.aof_set_pipeline(self._ctx, int(sub_pairs)))
 
     def set_profiling(self, on=True, kernels=None):
         """Time every kernel (kernels=None) or only the given kernel ids with HIP events."""

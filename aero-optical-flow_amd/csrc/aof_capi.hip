@@ -4,8 +4,10 @@
 // Launch sequence of aof_flow_batch_device (DESIGN.md "Kernels"):
 //   1 level :                      K2 search(L0) -> K3 reduce
 //   + mean  : memset sums -> K1 -> K2 search(L0) -> K3 reduce
-//   2 levels: [memset] -> K1 -> K2 search(L1) -> K3 reduce(L1: predictor)
-//                              -> K2 search(L0, shifted by predictor) -> K3 reduce
+//   2 levels: k_coarse (sums, pyramid, level-1 search and predictor of a pair in one workgroup)
+//             or [memset] -> K1 -> K2 search(L1) -> K3 reduce(L1: predictor),
+//             then K2 search(L0, shifted by predictor) -> K3 reduce
+//   small pairs (<= 128 per call, frames that fit LDS): k_flow_small, everything in one launch
 // Everything is enqueued on the caller's stream; nothing allocates or
 // synchronises, so the sequence can be captured into a hipGraph.
 #include <hip/hip_runtime.h>
@@ -24,6 +26,7 @@ struct aof_ctx {
     aof_params params;
     Grid g0, g1;
     int device;
+    int cus;                  // compute units of `device`
     bool force_generic;
     bool profiling;
     uint32_t profile_mask;
@@ -52,11 +55,6 @@ struct aof_ctx {
     hipGraphExec_t push_graph[2];
     bool graph_disabled;        // capture failed once: stay on the plain path
     bool capturing;
-    // two-level batches: coarse passes (K1, level-1 search and reduce) of sub-batch i+1 run on
-    // `aux` under the level-0 search of sub-batch i (DESIGN.md "C3 pipeline")
-    hipStream_t aux;
-    hipEvent_t *pipe_ev;        // [kPipeEvents]: fork + per-sub-batch coarse-done / fine-done
-    int64_t pipeline_pairs;     // sub-batch size: 0 = off, < 0 = automatic
     bool split_coarse;          // run K1 / level-1 search / level-1 reduce as separate kernels
     // reduction inside the flat lane8 search (no K3 launch): the pairs' vote records, zero at rest
     uint32_t *d_votes;
@@ -69,8 +67,6 @@ struct aof_ctx {
 
 constexpr int64_t kVotePairs = 8192;             // vote records per context (launches of more pairs keep K3)
 constexpr uint32_t kVoteStride = 128;            // words per record: 1 + 2 * 55 bins at the most (R = 13)
-constexpr int kPipeMaxSub = 64;                  // sub-batches per call at most
-constexpr int kPipeEvents = 1 + 2 * kPipeMaxSub;
 
 namespace {
 
@@ -135,47 +131,33 @@ SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const
     a.subpixel = p.subpixel;
     a.blocks = blocks; a.subdirs = p.subpixel ? subdirs : nullptr;
     a.pred = pred; a.sums = sums; a.level = level; a.n_pairs = n;
-    a.hist_parts = nullptr; a.hist_range = level_range(p, level);
-    a.prune = ctx->search_mode == AOF_SEARCH_PRUNED || ctx->search_mode == AOF_SEARCH_PRUNED_STRIPS;
+    a.hist_range = level_range(p, level);
+    a.prune = ctx->search_mode == AOF_SEARCH_PRUNED;
     return a;
 }
 
 constexpr int64_t kSmallMaxPairs = 128;   // one-launch path for small pairs: measured faster than the separate kernels up to here
 
-enum SearchKind { SK_TILE8, SK_TILE16, SK_LANE8_GROUP, SK_LANE8, SK_GENERIC };
+enum SearchKind { SK_TILE16, SK_LANE8_GROUP, SK_LANE8, SK_GENERIC };
 
 // Which search kernel serves these arguments (run_search, enqueue_level and aof_search_variant agree).
 SearchKind search_kind(const aof_ctx *ctx, const SearchArgs &a)
 {
     if (ctx->force_generic) return SK_GENERIC;
-    // The LDS-strip kernel serves the explicit ..._STRIPS modes; the default exhaustive search of
-    // 8x8 tiles runs lane-per-block straight from L2 (measured faster on every dense
-    // configuration: full lane use, no staging phases, no barriers).
-    const bool strips = ctx->search_mode == AOF_SEARCH_EXHAUSTIVE_STRIPS || ctx->search_mode == AOF_SEARCH_PRUNED_STRIPS;
-    // (tile8_geometry: the workspace layout reserved the strips' vote histograms for this level)
-    if (strips && tile8_supported(a) && tile8_geometry(ctx->params, a.level)) return SK_TILE8;
+    // 8x8 tiles run lane-per-block straight from L2 (measured faster than LDS-staged strips on every
+    // dense configuration: full lane use, no staging phases, no barriers)
     if (tile16_supported(a)) return SK_TILE16;
     if (lane8_supported(a)) return lane8_group(a) > 0 ? SK_LANE8_GROUP : SK_LANE8;
     return SK_GENERIC;
 }
 
-// Runs the level's search; *parts_used says whether the kernel wrote per-strip histograms
-// into `parts` (only the tile8 kernel does), in which case K3 sums those instead of the records.
-// *reduced: the search kernel also wrote the pairs' flow records (grouped lane8), no K3 follows.
-int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, uint32_t *parts,
-               const uint32_t **parts_used, int *nstrips, bool *reduced, hipStream_t s)
+// Runs the level's search.  *reduced: the search kernel also wrote the pairs' flow records (grouped
+// lane8, flat lane8 with the reduction in its launch), no K3 follows.
+int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, hipStream_t s)
 {
     int rc;
-    *parts_used = nullptr;
-    *nstrips = 0;
     *reduced = false;
     switch (search_kind(ctx, a)) {
-    case SK_TILE8:
-        a.hist_parts = parts;   // the strips vote (half-pixel offsets included): K3 sums them
-        *parts_used = parts;
-        *nstrips = plan_tile8(a.w, a.grid.nx, a.grid.ny).nstrips;
-        rc = launch_search_tile8(a, s);
-        break;
     case SK_TILE16:
         rc = launch_search_tile16(a, s);
         if (!rc && a.subpixel) rc = launch_refine(a, s);
@@ -242,17 +224,16 @@ FlowTail flow_tail(const aof_ctx *ctx, int level, aof_flow *flows, const aof_flo
 int enqueue_level(aof_ctx *ctx, int level, SearchArgs a, const FlowTail &tail, uint8_t *hist, int kid_search,
                   int kid_reduce, hipStream_t s)
 {
-    const uint32_t *parts = nullptr;
-    int nstrips = 0, rc;
+    int rc;
     bool reduced = false;
     {
         Timed t(ctx, kid_search, s);
-        rc = run_search(ctx, a, tail, reinterpret_cast<uint32_t *>(hist), &parts, &nstrips, &reduced, s);
+        rc = run_search(ctx, a, tail, &reduced, s);
         if (rc) return rc;
     }
     if (reduced) return 0;
     ReduceArgs r;
-    r.parts = parts; r.nstrips = nstrips;
+    r.parts = nullptr; r.nstrips = 0;
     r.blocks = a.blocks; r.subdirs = a.subdirs;
     r.value_threshold = value_threshold_u16(ctx->params);
     r.tail = tail; r.n_pairs = a.n_pairs;
@@ -285,7 +266,7 @@ int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, h
         c.blocks = v.blocks1 + first * ctx->g1.blocks();
         c.tail = flow_tail(ctx, 1, v.flows1 + first, nullptr);
         c.n_pairs = n;
-        c.first_generation = 0; c.stagger_groups = 0; c.stagger_ticks = 0;   // chosen by the launcher
+        c.first_generation = ctx->cus; c.stagger_groups = 0; c.stagger_ticks = 0;   // stagger chosen by the launcher
         if (coarse_fused_supported(c)) {
             Timed t(ctx, AOF_K_PYRAMID, s);
             const int rc = launch_coarse_fused(c, s);
@@ -348,20 +329,10 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
     std::memset(ctx, 0, sizeof(*ctx));
     ctx->params = *p;
     ctx->device = device;
+    ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     grid_for_level(*p, 0, &ctx->g0);
     if (p->pyramid_levels == 2) grid_for_level(*p, 1, &ctx->g1);
     std::snprintf(ctx->err, sizeof(ctx->err), "ok");
-    ctx->pipeline_pairs = 0;   // opt-in: measured slower than one pass on this stack
-    if (p->pyramid_levels == 2) {
-        // made here, not on first use: the batch path must stay capturable into a hipGraph
-        DeviceGuard guard(device);
-        ctx->pipe_ev = new (std::nothrow) hipEvent_t[kPipeEvents]();
-        bool ok = ctx->pipe_ev && hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; ok && i < kPipeEvents; i++)
-            ok = hipEventCreateWithFlags(&ctx->pipe_ev[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { aof_destroy(ctx); return -EIO; }
-    }
-
     if (p->tile == 8 && p->search == 4) {   // the flat lane8 search can reduce in its own launch
         DeviceGuard guard(device);
         const size_t bytes = (size_t)kVotePairs * kVoteStride * sizeof(uint32_t);
@@ -389,11 +360,6 @@ void aof_destroy(aof_ctx *ctx)
                 for (int e = 0; e < 2; e++)
                     if (ctx->ev[k][r][e]) (void)hipEventDestroy(ctx->ev[k][r][e]);
         delete[] ctx->ev;
-    }
-    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
-    if (ctx->pipe_ev) {
-        for (int i = 0; i < kPipeEvents; i++) if (ctx->pipe_ev[i]) (void)hipEventDestroy(ctx->pipe_ev[i]);
-        delete[] ctx->pipe_ev;
     }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 2; i++) if (ctx->push_graph[i]) (void)hipGraphExecDestroy(ctx->push_graph[i]);
@@ -429,7 +395,6 @@ const char *aof_search_variant(const aof_ctx *ctx)
     SearchArgs probe = search_args(ctx, 0, nullptr, nullptr, (int64_t)p.width * p.height, nullptr, nullptr,
                                    nullptr, nullptr, 1);
     switch (search_kind(ctx, probe)) {
-    case SK_TILE8: return "tile8_lds";
     case SK_TILE16: return "tile16_lds";
     case SK_GENERIC: return "generic";
     default: return "lane8";
@@ -448,7 +413,7 @@ int aof_set_force_generic(aof_ctx *ctx, int on)
 
 int aof_set_search_mode(aof_ctx *ctx, int mode)
 {
-    if (!ctx || mode < AOF_SEARCH_EXHAUSTIVE || mode > AOF_SEARCH_PRUNED_STRIPS) return -EINVAL;
+    if (!ctx || mode < AOF_SEARCH_EXHAUSTIVE || mode > AOF_SEARCH_PRUNED) return -EINVAL;
     if (mode != ctx->search_mode) {  // captured graphs hold the old kernel
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
@@ -575,44 +540,9 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         }
     }
 
-    // Two levels: the coarse passes are HBM-bound (K1 streams both frames) and the level-0
-    // search is VALU-bound, so a large batch is cut into sub-batches and the coarse passes of
-    // sub-batch i+1 run on a second stream under the level-0 search of sub-batch i.  Sub-batches
-    // are sized so that the frames K1 has just streamed are still in the 256 MiB memory-side
-    // cache when the level-0 search reads them again; the coarse stream is held two sub-batches
-    // ahead at most for the same reason.
-    int64_t sub = 0;
-    if (two && ctx->aux && ctx->pipeline_pairs != 0) {
-        sub = ctx->pipeline_pairs;
-        if (sub < 0) {
-            const int64_t pair_bytes = 2 * (int64_t)p.width * p.height;
-            sub = (64ll << 20) / pair_bytes;
-            if (sub < 16) sub = 16;
-        }
-        if ((n_pairs + sub - 1) / sub > kPipeMaxSub) sub = (n_pairs + kPipeMaxSub - 1) / kPipeMaxSub;
-        if (n_pairs < 2 * sub) sub = 0;   // nothing to overlap
-    }
-    if (sub == 0) {
-        rc = enqueue_coarse(ctx, v, 0, n_pairs, s);
-        if (!rc) rc = enqueue_fine(ctx, v, 0, n_pairs, s);
-        return rc;
-    }
-    hipEvent_t *ev = ctx->pipe_ev;
-    const int nsub = (int)((n_pairs + sub - 1) / sub);
-    HIP_TRY(ctx, hipEventRecord(ev[0], s));             // fork: aux starts behind the caller's stream
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ev[0], 0));
-    for (int i = 0; i < nsub; i++) {
-        const int64_t first = (int64_t)i * sub, count = n_pairs - first < sub ? n_pairs - first : sub;
-        if (i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ev[2 + 2 * (i - 2)], 0));  // fine(i-2) done
-        rc = enqueue_coarse(ctx, v, first, count, ctx->aux);
-        if (rc) return rc;
-        HIP_TRY(ctx, hipEventRecord(ev[1 + 2 * i], ctx->aux));
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ev[1 + 2 * i], 0));   // join (the last one joins aux for good)
-        rc = enqueue_fine(ctx, v, first, count, s);
-        if (rc) return rc;
-        if (i + 2 < nsub) HIP_TRY(ctx, hipEventRecord(ev[2 + 2 * i], s));
-    }
-    return 0;
+    rc = enqueue_coarse(ctx, v, 0, n_pairs, s);
+    if (!rc) rc = enqueue_fine(ctx, v, 0, n_pairs, s);
+    return rc;
 }
 
 int aof_set_split_coarse(aof_ctx *ctx, int on)
@@ -629,13 +559,6 @@ int aof_set_reduce_fusion(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
     ctx->separate_reduce = on == 0;
-    return 0;
-}
-
-int aof_set_pipeline(aof_ctx *ctx, int64_t sub_pairs)
-{
-    if (!ctx) return -EINVAL;
-    ctx->pipeline_pairs = sub_pairs;
     return 0;
 }
 

@@ -37,15 +37,7 @@ struct Grid {
     AOF_HD int32_t blocks() const { return nx * ny; }
 };
 
-// Strip plan of the tile8 search kernel: rb block rows per workgroup.
-struct Tile8Plan {
-    int rb, threads, nstrips, dyg;
-    size_t lds;
-};
-
 // Host-only parameter logic (aof_params.cpp).
-Tile8Plan plan_tile8(int w, int nx, int ny);   // rb == 0: no feasible plan
-bool tile8_geometry(const aof_params &p, int level);  // level can run the tile8 kernel
 int grid_for_level(const aof_params &p, int level, Grid *g);
 int level_range(const aof_params &p, int level);  // histogram half-range R
 int value_threshold_u16(const aof_params &p);     // SAD gate clamped to the u16 record
@@ -87,9 +79,8 @@ struct SearchArgs {
     const uint32_t *sums;      // [n_pairs][2][2] pixel sums, or nullptr when not equalising
     int32_t level;             // which sums column to use
     int64_t n_pairs;
-    uint32_t *hist_parts;      // tile8 only: [n_pairs][nstrips][2][2*(2R+1)+1] per-strip vote histograms
     int32_t hist_range;        // R
-    int32_t prune;             // exact partial-distortion elimination (lane8, tile8, tile16)
+    int32_t prune;             // exact partial-distortion elimination (lane8, tile16)
     FastDiv div_nb, div_nx;    // lane8: filled by its launchers (item -> pair, block -> row)
 };
 
@@ -99,8 +90,8 @@ struct ReduceArgs {
     int32_t value_threshold;
     FlowTail tail;
     int64_t n_pairs;
-    const uint32_t *parts;     // per-strip histograms written by the tile8 search (then blocks are not read)
-    int32_t nstrips;
+    const uint32_t *parts;     // per-chunk histograms of the first step of a two-step reduction (then blocks are not read)
+    int32_t nstrips;           // chunks per pair
     uint32_t *chunk_parts;     // large grids: scratch for per-chunk histograms ([n_pairs][chunks][2][bins]), or nullptr
 };
 
@@ -119,7 +110,8 @@ struct CoarseArgs {
     FlowTail tail;             // level-1 flows: the predictor
     int64_t n_pairs;
     FastDiv div_nb, div_nx, div_chunks;   // filled by the launcher
-    int32_t first_generation, stagger_groups, stagger_ticks;   // launcher: start-up stagger (0 = choose)
+    int32_t first_generation;  // workgroups of the first generation = CUs of the device (set by the caller)
+    int32_t stagger_groups, stagger_ticks;   // start-up stagger; stagger_groups == 0: the launcher chooses
     int32_t rows_per_sweep;    // launcher: level-1 rows one sweep of the workgroup's lanes covers
 };
 
@@ -152,10 +144,6 @@ int launch_search_generic(const SearchArgs &a, void *stream);
 // K2b: half-pixel refinement of records written by an integer search (tile 8 or 16; today only
 // the 16x16 kernel needs it); fills a.subdirs.
 int launch_refine(const SearchArgs &a, void *stream);
-// LDS-tiled lane-per-block kernel for B=8, S=4 on a dense grid whose rows are a multiple of
-// 16 bytes, half-pixel refinement included.  tile8_supported() says whether `a` qualifies.
-bool tile8_supported(const SearchArgs &a);
-int launch_search_tile8(const SearchArgs &a, void *stream);
 // Lane-per-block kernel straight from global memory for B=8, S=4 on ANY grid / width /
 // predictor (sparse PX4Flow grid, rows that are no multiple of 16 bytes), half-pixel refinement
 // included.

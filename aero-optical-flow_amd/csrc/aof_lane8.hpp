@@ -271,13 +271,11 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
             win[s] = make_uint4(v.x, v.y, v.z, v.w);
         }
     }
-#ifndef AOF_LAB_TWO_TRIPS
     // ONE memory round trip: left alone, the compiler sinks the window loads (and half of the tile
     // loads) below the gate's branch, so a wave first waits for four tile rows, gates, and only
     // then requests the other twenty rows.  Naming the last window row here keeps all 24 loads
     // in front of the gate (they return in order: one wait for everything).
     if (inside) asm volatile("" : "+v"(win[15].w));
-#endif
     uint32_t gradient = 0;
     if (inside) gradient = gradient_gate(ref);
     const bool need = inside && gradient >= (uint32_t)a.feature_threshold;

@@ -42,67 +42,6 @@ int value_threshold_u16(const aof_params &p)
     return p.value_threshold > 0xFFFF ? 0xFFFF : p.value_threshold;
 }
 
-#ifdef AOF_LAB  // experiment knobs of tools/k2_lab.hip; never defined in the product build
-int g_lab_rb = 0, g_lab_dyg = 0;
-#endif
-
-// Pick the strip height that keeps most lanes busy over the whole frame.  Workgroups
-// are whole multiples of 256 threads (one wave per SIMD): measured on MI355X, a
-// 5-wave workgroup with better lane use (rb=4 at VGA, 97 %) ran 33 % slower than the
-// 4-wave one (rb=3, 91 %) because fewer workgroups fit a CU and staging stops
-// overlapping with the search (profiles/r01_b_k2_lab.txt).  One lane per block
-// (dyg = 9): three lanes per block measured 11 % slower (profiles/r01_c_k2_lab_dyg.txt).
-static Tile8Plan plan_tile8_budget(int w, int nx, int ny, size_t kLdsBudget)
-{
-    const int kMaxThreads = 512;
-    Tile8Plan best = {0, 0, 0, 0, 0};
-    double best_eff = -1.0;
-    int dyg = 9;
-#ifdef AOF_LAB
-    if (g_lab_dyg) dyg = g_lab_dyg;
-#endif
-    for (int rb = 1; rb <= 16; rb++) {
-        const int items = rb * nx * (9 / dyg);
-        int threads = (items + 255) / 256 * 256;
-#ifdef AOF_LAB
-        if (g_lab_rb && rb != g_lab_rb) continue;
-        if (g_lab_rb) threads = (items + 63) / 64 * 64;
-#endif
-        // cur rows + prev rows + 16 pad, per-block best keys, vote histograms (<= 2*104 bins)
-        // (+ two ring rows and the lead pad of the half-pixel variant)
-        const size_t lds = (size_t)(16 * rb + 8 + 2) * w + 16 + 16 + 4 * (size_t)(rb * nx) + 4 * 2 * 104;
-        if (threads > kMaxThreads || lds > kLdsBudget) break;
-        const int nstrips = (ny + rb - 1) / rb;
-        const double eff = (double)nx * ny * (9 / dyg) / ((double)nstrips * threads);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = {rb, threads, nstrips, dyg, lds}; }
-    }
-    return best;
-}
-
-Tile8Plan plan_tile8(int w, int nx, int ny)
-{
-    // two workgroups per CU at the least; very wide rows (4K frames: one block row is 100 KB
-    // of tiles) get the whole LDS of a CU rather than no strip plan at all
-    Tile8Plan p = plan_tile8_budget(w, nx, ny, 80 * 1024);
-    if (p.rb == 0) p = plan_tile8_budget(w, nx, ny, 156 * 1024);
-    return p;
-}
-
-bool tile8_geometry(const aof_params &p, int level)
-{
-    if (p.tile != 8 || p.search != 4) return false;
-    const int w = p.width >> level;
-    if (w % 16) return false;
-    Grid g;
-    if (grid_for_level(p, level, &g)) return false;
-    // The same shape test as tile8_supported (k_search_tile8.hip), NOT the grid mode: a published
-    // sparse grid whose step comes out as 8 from origin 4 (+1) is such a grid too, the strip kernel
-    // takes it, and its per-strip histograms need their workspace.
-    const int org = p.subpixel ? 1 : 0;
-    if (g.x0 != 4 + org || g.y0 != 4 + org || g.step_x != 8 || g.step_y != 8) return false;
-    return plan_tile8(w, g.nx, g.ny).rb > 0;
-}
-
 // K3 on grids beyond kReduceChunk*2 blocks runs in two steps: one workgroup per chunk of records
 // votes into a partial histogram, then the usual per-pair workgroup sums the chunks.
 int reduce_chunks(int nblocks)
@@ -119,18 +58,14 @@ using namespace aof;
 
 namespace aof {
 
-// Bytes of per-pair vote-histogram scratch of a level: per-strip histograms of the tile8 search
-// or per-chunk histograms of the two-step reduction of large grids, whichever is larger.
+// Bytes of per-pair vote-histogram scratch of a level: the per-chunk histograms of the two-step
+// reduction of large grids (0 for grids one reduction workgroup reads alone).
 size_t hist_bytes_per_pair(const aof_params &p, int level)
 {
     Grid g;
     if (grid_for_level(p, level, &g)) return 0;
     const size_t bins = 2 * (2 * (size_t)level_range(p, level) + 1) + 1;
-    size_t bytes = 0;
-    if (tile8_geometry(p, level))
-        bytes = (size_t)plan_tile8(p.width >> level, g.nx, g.ny).nstrips * 2 * bins * sizeof(uint32_t);
-    const size_t need = (size_t)reduce_chunks(g.blocks()) * 2 * bins * sizeof(uint32_t);
-    return need > bytes ? need : bytes;
+    return (size_t)reduce_chunks(g.blocks()) * 2 * bins * sizeof(uint32_t);
 }
 
 }  // namespace aof

@@ -23,6 +23,7 @@
 
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
+#include "aof_lab_hooks.hpp"
 #include "aof_reduce.hpp"
 
 namespace aof {
@@ -44,16 +45,6 @@ __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
     return __builtin_amdgcn_qsad_pk_u16_u8(window, ref, acc);
 }
 __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | lo; }
-
-#ifdef AOF_LAB   // tools/coarse_lab.hip: in-kernel phase stamps; never defined in the product build
-__device__ unsigned long long *g_lab_stamps;   // [workgroups][8]
-#define LAB_STAMP(k)                                                                          \
-    do {                                                                                      \
-        if (g_lab_stamps && threadIdx.x == 0) g_lab_stamps[pair * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define LAB_STAMP(k) do { } while (0)
-#endif
 
 // Workgroup barrier for data exchanged through LDS only.  __syncthreads() carries a workgroup
 // fence, for which the compiler drains EVERY outstanding vector-memory operation (s_waitcnt
@@ -182,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
     const int64_t next = pair + gridDim.x < a.n_pairs ? pair + gridDim.x : pair;   // (last pair: harmless re-reads)
     uint32_t *hist = votes0 + par * kVoteWords;              // [2][kMaxBins]
     uint32_t *sums = hist + 2 * kMaxBins;                    // [4] pixel sums, [3] vote sums
-    LAB_STAMP(0);
+    AOF_LAB_STAMP(pair, 0);
     sum_p0 = sum_p1 = sum_c0 = sum_c1 = 0;
 #pragma unroll 1
     for (int k0 = 0; k0 < nk_pad; k0 += 2 * kUnroll) {
@@ -198,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
         atomicAdd(&sums[2], sum_c0); atomicAdd(&sums[3], sum_c1);
     }
     lds_barrier();
-    LAB_STAMP(1);
+    AOF_LAB_STAMP(pair, 1);
     if (tid == 0) {   // (wave-uniform addresses: nothing for the compiler to keep per lane across the pair loop)
         if (a.sums) *reinterpret_cast<uint4 *>(a.sums + pair * 4) = make_uint4(sums[0], sums[1], sums[2], sums[3]);
     }
@@ -234,7 +225,7 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
         keys[blk] = diff >= (uint32_t)a.feature_threshold ? kOpen : kGated;
     }
     lds_barrier();
-    LAB_STAMP(2);
+    AOF_LAB_STAMP(pair, 2);
 
     // ---- phase 3: one lane per (dy row, block) item ----
     const int items = 9 * nb;
@@ -273,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
         atomicMin(&keys[blk], best);
     }
     lds_barrier();
-    LAB_STAMP(3);
+    AOF_LAB_STAMP(pair, 3);
 
     // ---- phase 4: records, votes, predictor ----
     const int centre = 2 * a.tail.range + 1, n = 2 * centre + 1;
@@ -309,9 +300,9 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
         atomicAdd(&vs[2], cnt);
     }
     lds_barrier();
-    LAB_STAMP(4);
+    AOF_LAB_STAMP(pair, 4);
     if (tid < 64) finalise_flow_wave(a.tail, pair, hist, hist + kMaxBins, vs);   // (kMaxBins = 64 bins at most)
-    LAB_STAMP(5);
+    AOF_LAB_STAMP(pair, 5);
     (void)n;
     // (no barrier: the next pair votes into the other set; this one is cleared two barriers from now)
     }   // next pair of this workgroup
@@ -359,16 +350,10 @@ int launch_coarse_fused(const CoarseArgs &a, void *stream)
         }
         k.rows_per_sweep = best;
     }
-    if (k.first_generation == 0) {   // (the lab tool sets its own)
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-            if (cus <= 0) cus = 256;
-        }
-        k.first_generation = cus;
-        k.stagger_groups = a.n_pairs >= 2 * cus ? kStaggerGroups : 1;
+    // first_generation: the CU count of the context's device, set by the caller
+    if (k.first_generation <= 0) return (int)hipErrorInvalidValue;
+    if (k.stagger_groups == 0) {   // (the lab tool sets its own)
+        k.stagger_groups = a.n_pairs >= 2 * (int64_t)k.first_generation ? kStaggerGroups : 1;
         // one group's share of the stream phase: the pair's bytes at the rate a CU reaches when
         // only 1/groups of the chip streams
         k.stagger_ticks = (int32_t)((int64_t)2 * a.w * a.h * 100 / kStaggerBytesPerUs);

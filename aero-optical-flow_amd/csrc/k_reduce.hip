@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
     sync();
 
     if (a.parts) {
-        // The tile8 search already voted per strip: sum the strips' histograms.  Count and
+        // A first step (k_reduce_chunk) already voted per chunk of records: sum the chunks' histograms.  Count and
         // shift sums follow from the histogram: count = sum h[k], sum2 = sum (k - centre) h[k].
         const uint32_t *parts = a.parts + (size_t)pair * a.nstrips * (size_t)(2 * n);
         for (int k = tid; k < 2 * n; k += GROUP) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(ReduceArgs a)
 }
 
 // Large grids (a 4K frame has 128 000 blocks): one workgroup per chunk of 4 096 records votes
-// into its own histogram; k_reduce then sums the chunks exactly like the strip kernel's votes.
+// into its own histogram; k_reduce then sums the chunks' histograms.
 __global__ __launch_bounds__(kThreads) void k_reduce_chunk(ReduceArgs a, int chunks)
 {
     __shared__ uint32_t hist[2][kMaxHist];

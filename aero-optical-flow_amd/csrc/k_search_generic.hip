@@ -10,8 +10,8 @@
 // realigned with v_alignbyte_b32 by the lane's own byte phase and summed with
 // v_sad_u8 (4 pixels per instruction).  The half-pixel refinement spreads its
 // 8 directions x B rows over the wave and adds the rows with three shuffles.
-// This kernel favours generality; the dense 8x8/+-4 configuration the metric is
-// quoted on runs k_search_tile8 instead.
+// This kernel favours generality; the 8x8/+-4 configurations the metric is quoted on
+// run k_search_lane8 instead, 16x16/+-8 runs k_search_tile16.
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 

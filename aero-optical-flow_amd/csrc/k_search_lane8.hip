@@ -16,14 +16,15 @@
 // Why no LDS staging: on a dense grid neighbouring lanes read neighbouring 8-byte columns, so
 // a wave's row load is one contiguous run; vertically adjacent blocks share half their rows
 // through L1/L2 (workgroup ids are remapped so that consecutive block rows of a pair stay on one
-// XCD); HBM sees every frame byte once (PMC: 624 MB read per 629 MB of frames).  Against the
-// LDS-strip kernel (k_search_tile8, this round's first dominant kernel) all 64 lanes of every
+// XCD); HBM sees every frame byte once (PMC: 624 MB read per 629 MB of frames).  Against an
+// LDS-strip kernel (round 1's first dominant kernel, removed in round 3) all 64 lanes of every
 // wave work, nothing waits at a barrier and there is no staging phase to hide: 8 % faster on
 // C2, 16 % with half-pixel refinement (profiles/r01_p_lane8_vs_strips.txt).
 //
-// Variants: k_search_lane8 (flat items, K3 follows), k_flow_lane8 (grids of 8..256 blocks: a
-// workgroup owns whole pairs and finalises their flow records itself), k_search_lane8_pruned
-// (AOF_SEARCH_PRUNED: exact partial-distortion elimination, see pruned_row below).
+// Variants: k_search_lane8 (flat items, K3 follows), k_flow_lane8_flat (flat items, the reduction in
+// the same launch: aof_set_reduce_fusion), k_flow_lane8 (grids of 8..256 blocks: a workgroup owns
+// whole pairs and finalises their flow records itself), k_search_lane8_pruned (AOF_SEARCH_PRUNED:
+// exact partial-distortion elimination, see pruned_row in aof_lane8.hpp).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 #include "aof_lane8.hpp"

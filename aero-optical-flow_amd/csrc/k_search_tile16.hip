@@ -21,10 +21,7 @@ namespace {
 
 constexpr int kThreads = 512;
 constexpr int kSide = 17;  // 2S+1
-#ifndef AOF_LAB_BOUND_ROWS
-#define AOF_LAB_BOUND_ROWS 2
-#endif
-constexpr int kBoundRows = AOF_LAB_BOUND_ROWS;  // tile rows summed for the lower bound of the pruned search
+constexpr int kBoundRows = 2;  // tile rows summed for the lower bound of the pruned search
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 {
@@ -120,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * a.h));
 
     // Level 0 under a predictor (px, py): the block row's windows move by py rows and px columns.
-    // As in k_search_tile8 the cur rows are staged PRE-SHIFTED by px mod 16, so that LDS column c
+    // The cur rows are staged PRE-SHIFTED by px mod 16, so that LDS column c
     // holds frame column c + sh and every window is again 16-byte aligned at LDS column
     // 16*(bx + (px >> 4)); rows pushed outside the frame skip the whole block row.
     int px = 0, py = 0;

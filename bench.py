@@ -337,7 +337,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1", "derotate"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
-    ap.add_argument("--search", default="exhaustive", choices=["exhaustive", "pruned", "strips", "pruned_strips"],
+    ap.add_argument("--search", default="exhaustive", choices=["exhaustive", "pruned"],
                     help="exhaustive (default, the data-independent rate the metric is quoted on) or "
                          "pruned: exact partial-distortion elimination, same records, rate depends on "
                          "the images (fast on these clean synthetic translations)")
@@ -354,9 +354,6 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = rehearsal of the N>1 "
                          "control flow with several ranks sharing the GPUs that exist")
-    ap.add_argument("--pipeline", type=int, default=0,
-                    help="two-level workloads: pairs per pipelined sub-batch (coarse passes of sub-batch i+1 on a "
-                         "second stream under the level-0 search of sub-batch i); 0 = off (default), -1 = automatic")
     ap.add_argument("--coarse", default="auto", choices=["auto", "split"],
                     help="two-level workloads: how the coarse passes run -- auto (the fused kernel k_coarse where the "
                          "geometry allows) or split (K1 / level-1 search / K3 as separate kernels)")
@@ -420,13 +417,8 @@ def main():
     def configure(e):
         if args.search == "pruned":
             e.set_search_mode(aof.SEARCH_PRUNED)
-        elif args.search == "strips":
-            e.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
-        elif args.search == "pruned_strips":
-            e.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
         if args.force_generic:
             e.force_generic(True)
-        e.set_pipeline(args.pipeline)
         e.set_reduce_fusion(reduce_mode == "fused")
         if args.coarse != "auto":
             e.set_split_coarse(True)
@@ -553,12 +545,12 @@ def main():
     fence()
     # HIP events around the dominant kernel (K2, level 0) on the launch stream.  Steps of a millisecond
     # or so carry them inside the timed region; every event pair costs the stream a few microseconds of
-    # serialisation, so short steps (and replayed graphs, pipelined sub-batches, several lanes) are timed
+    # serialisation, so short steps (and replayed graphs, several lanes) are timed
     # without events and K2 is measured in a second pass of the same K steps on lane 0 right after it.
     eng.set_profiling(True, kernels=[aof.K_SEARCH])
     lanes[0].enqueue[0]()
     fence()
-    lps = max(1, len(eng.profile_ms(aof.K_SEARCH)))   # K2 launches per step (pipelined sub-batches)
+    lps = max(1, len(eng.profile_ms(aof.K_SEARCH)))   # K2 launches per step (a batch of more than 2^31 blocks is cut into several)
     events_in_timed_region = lps == 1 and not use_graph and not multi and n * nb >= (1 << 21)
     eng.set_profiling(events_in_timed_region, kernels=[aof.K_SEARCH])
     for _ in range(args.warmup):
@@ -654,7 +646,7 @@ def main():
                      "achieved_step": round(achieved_step, 1), "frac_step": round(achieved_step / HBM_PEAK_GBS, 4),
                      "kernel": "k_search (K2)", "kernel_ms": round(k2_ms, 5),
                      "kernel_ms_from": "HIP events on the launch stream inside the timed region" if events_in_timed_region
-                     else f"HIP events in a second pass of the same {args.steps} steps (sum of the {lps} sub-batch "
+                     else f"HIP events in a second pass of the same {args.steps} steps (sum of the {lps} "
                           "launches of a step, which other kernels overlap): quote frac_step for this workload",
                      "algorithmic_bytes_per_pair": alg_bytes, "pairs_per_launch": n,
                      # nominal abs-diffs of the exhaustive scan; meaningless when candidates are pruned

@@ -86,8 +86,8 @@ typedef struct aof_ws_layout {
     size_t l1_flows;  /* aof_flow [n_pairs] (pred_x/pred_y = predictor) */
     size_t l0_blocks; /* aof_block [n_pairs][nb0] when the caller passes none */
     size_t l0_subdirs;/* u8 [n_pairs][nb0] when the caller passes none */
-    size_t l0_hist;   /* u32 [n_pairs][strips0][2][bins0]: per-strip vote histograms (tile8 kernel) */
-    size_t l1_hist;   /* u32 [n_pairs][strips1][2][bins1] */
+    size_t l0_hist;   /* u32 [n_pairs][chunks0][2][bins0]: per-chunk vote histograms (grids beyond 8 192 blocks) */
+    size_t l1_hist;   /* u32 [n_pairs][chunks1][2][bins1] */
 } aof_ws_layout;
 
 typedef struct aof_ctx aof_ctx;
@@ -120,25 +120,20 @@ int aof_create(const aof_params *p, int device, aof_ctx **out);
 void aof_destroy(aof_ctx *ctx);
 const char *aof_last_error(const aof_ctx *ctx);
 int aof_get_params(const aof_ctx *ctx, aof_params *out);
-/* Name of the search kernel variant the context selected ("tile8_lds", "generic", ...). */
+/* Name of the search kernel variant the context selected ("lane8", "tile16_lds", "generic"). */
 const char *aof_search_variant(const aof_ctx *ctx);
 /* Force the generic search kernel (tests compare the two device paths). */
 int aof_set_force_generic(aof_ctx *ctx, int on);
-/* Search strategy for 8x8 tiles, +-4.  All three return bit-identical records.
- * EXHAUSTIVE (default): all 81 candidates of every block are summed completely -- a
- *   data-independent rate, the one BASELINE's metric is quoted on.  The library picks the
- *   fastest kernel for the configuration (lane-per-block from L2 for 8x8 tiles).
- * PRUNED: exact partial-distortion elimination.  The nine dy rows are
- *   visited outwards from dy = 0; after two of a row's eight row pairs a wave drops the row
- *   when no lane's partial SAD can still beat its best (a partial sum only grows).  The rate
- *   then depends on the images: fast when blocks have a clear match near the centre, slower
- *   than the exhaustive search on noise.
- * EXHAUSTIVE_STRIPS: the exhaustive search in the LDS-strip kernel (kept for comparison and as
- *   the per-wave fallback of PRUNED). */
+/* Search strategy.  Both return bit-identical records.
+ * EXHAUSTIVE (default): all candidates of every block are summed completely -- a data-independent
+ *   rate, the one BASELINE's metric is quoted on.
+ * PRUNED: exact partial-distortion elimination (8x8 tiles on grids of more than 256 blocks, and
+ *   16x16 tiles).  The dy rows are visited outwards from dy = 0; after a few of a row's tile rows a
+ *   wave drops the row when no lane's partial SAD can still beat its best (a partial sum only grows).
+ *   The rate then depends on the images: fast when blocks have a clear match near the centre, slower
+ *   than the exhaustive search on noise. */
 #define AOF_SEARCH_EXHAUSTIVE 0
 #define AOF_SEARCH_PRUNED 1
-#define AOF_SEARCH_EXHAUSTIVE_STRIPS 2
-#define AOF_SEARCH_PRUNED_STRIPS 3 /* the pruned search in the LDS-strip kernel (comparison) */
 int aof_set_search_mode(aof_ctx *ctx, int mode);
 
 /* ---- the hot path, device-resident (batched) ----
@@ -176,17 +171,6 @@ int aof_set_split_coarse(aof_ctx *ctx, int on);
  * concurrently with each other or with eager calls on it.  on = 0 launches K3 as a separate kernel
  * instead (tests compare the two); 1 = default. */
 int aof_set_reduce_fusion(aof_ctx *ctx, int on);
-
-/* Two-level configurations cut a large batch into sub-batches and run the HBM-bound coarse
- * passes (pixel sums + 2x2 pyramid, level-1 search and reduce) of sub-batch i+1 on an internal
- * second stream under the VALU-bound level-0 search of sub-batch i; everything still joins the
- * caller's stream before aof_flow_batch_device's work ends, and the call stays capturable.
- * sub_pairs: pairs per sub-batch; 0 = off (one pass over the whole batch: the default, because
- * on ROCm 7.2 the cross-stream dependencies cost more than the overlap gains -- DESIGN.md
- * section 8), < 0 = automatic (about 64 MiB of frames per sub-batch, so that the level-0
- * search finds the frames K1 streamed a moment ago in the memory-side cache).  Results do
- * not depend on it. */
-int aof_set_pipeline(aof_ctx *ctx, int64_t sub_pairs);
 
 /* ---- host-buffer conveniences (what the C++ facade calls) ----
  * Synchronous: copy in, run the kernels above, copy out.  blocks/subdirs may be NULL. */

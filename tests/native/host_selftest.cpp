@@ -37,11 +37,10 @@ int main()
             const int lx = g[0] + (g[4] - 1) * g[2], ly = g[1] + (g[5] - 1) * g[3];
             if (g[0] - p.search - m < 0 || lx + p.tile + p.search + m > w) return 3;
             if (g[1] - p.search - m < 0 || ly + p.tile + p.search + m > h) return 4;
-            if (aof::tile8_geometry(p, l)) {
-                aof::Tile8Plan pl = aof::plan_tile8(w, g[4], g[5]);
-                if (pl.rb < 1 || pl.threads % 256 || pl.nstrips * pl.rb < g[5] || pl.lds > 80 * 1024) return 5;
-                if (pl.rb * g[4] > pl.threads) return 6;
-            }
+            // the two-step reduction of large grids covers every block with its chunks
+            const int chunks = aof::reduce_chunks(g[4] * g[5]);
+            if (chunks < 0 || (chunks > 0 && (long long)chunks * 4096 < (long long)g[4] * g[5])) return 5;
+            if (aof::hist_bytes_per_pair(p, l) != (size_t)chunks * 2 * (2 * (2 * (size_t)aof::level_range(p, l) + 1) + 1) * 4) return 6;
         }
         aof_ws_layout L;
         if (aof_workspace_layout(&p, (int64_t)(rnd() % 5000), &L)) return 7;

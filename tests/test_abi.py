@@ -87,23 +87,22 @@ def test_workspace_layout(aof):
     assert aof.workspace_layout(aof.default_params(64, 64), 0).total_bytes >= 256
 
 
-def test_workspace_layout_reserves_strip_histograms_by_grid_shape(aof):
-    """The strip kernel is chosen by the SHAPE of the grid (origin 4 or 5, step 8), so the layout has
-    to reserve its per-strip vote histograms by shape too: a published sparse grid can have that shape."""
+def test_workspace_layout_reserves_chunk_histograms_for_large_grids(aof):
+    """Grids of more than 8 192 blocks are reduced in two steps (one workgroup per chunk of 4 096 records
+    votes into its own histogram, then one per pair sums them): the layout reserves those per-chunk
+    histograms, and nothing for grids one workgroup reads alone."""
     for levels in (1, 2):
-        sparse = aof.px4flow_params(64, 64, num_blocks=6, pyramid_levels=levels)
-        assert aof.grid(sparse, 0)[:4] == (5, 5, 8, 8)
-        dense = aof.default_params(64, 64, subpixel=1, pyramid_levels=levels)
-        assert aof.grid(dense, 0) == aof.grid(sparse, 0)
+        big = aof.default_params(1024, 768, pyramid_levels=levels)        # 127 x 95 = 12 065 blocks
+        nb = aof.grid(big, 0)[4] * aof.grid(big, 0)[5]
+        assert nb > 8192
+        chunks = (nb + 4095) // 4096
+        bins = 2 * (2 * (4 if levels == 1 else 13) + 1) + 1
         for n in (1, 2, 9):
-            Ls, Ld = aof.workspace_layout(sparse, n), aof.workspace_layout(dense, n)
-            size = lambda L: (L.l1_hist if levels == 2 else L.total_bytes) - L.l0_hist   # level 0's region
-            assert size(Ls) == size(Ld)
-            bins = 2 * (2 * (4 if levels == 1 else 13) + 1) + 1
-            assert size(Ls) >= n * 2 * bins * 4   # at least one strip per pair
-    other = aof.px4flow_params(64, 64)   # the default 5x5 grid (step 10) is no strip grid
-    Lo = aof.workspace_layout(other, 2)
-    assert Lo.total_bytes == Lo.l0_hist or Lo.total_bytes - Lo.l0_hist < 256
+            L = aof.workspace_layout(big, n)
+            size = (L.l1_hist if levels == 2 else L.total_bytes) - L.l0_hist   # level 0's region
+            assert size >= n * chunks * 2 * bins * 4
+    vga = aof.workspace_layout(aof.default_params(640, 480), 2)
+    assert vga.total_bytes == vga.l0_hist or vga.total_bytes - vga.l0_hist < 256
 
 
 def test_strerror(aof):

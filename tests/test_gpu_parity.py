@@ -10,15 +10,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_gpu(aof, p, prevs, curs, device, force_generic=False, want_ws=False, strips=False, split_coarse=False):
+def run_gpu(aof, p, prevs, curs, device, force_generic=False, want_ws=False, fused_reduce=False, split_coarse=False):
     import torch
     eng = aof.FlowEngine(p, 0)
     if force_generic:
         eng.force_generic(True)
     if split_coarse:
         eng.set_split_coarse(True)
-    if strips:
-        eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
+    if fused_reduce:   # the flat lane8 search reduces in its own launch (grids of more than 256 blocks)
+        eng.set_reduce_fusion(True)
     tp = torch.from_numpy(np.ascontiguousarray(prevs)).to(device)
     tc = torch.from_numpy(np.ascontiguousarray(curs)).to(device)
     blocks, flows, ws = eng.flow_batch(tp, tc)
@@ -72,9 +72,6 @@ def test_c1_64x64_dense(aof, orc, synth, gpu_device):
     got = run_gpu(aof, p, prevs, curs, gpu_device)
     assert got["variant"] == "lane8"
     check_against_oracle(aof, orc, p, prevs, curs, got)
-    strip = run_gpu(aof, p, prevs, curs, gpu_device, strips=True)
-    assert strip["variant"] == "tile8_lds"
-    assert strip["blocks"].tobytes() == got["blocks"].tobytes() and strip["flows"].tobytes() == got["flows"].tobytes()
     # analytic known answer, independent of any implementation
     for i in range(16):
         assert (got["blocks"][i]["dx"] == shifts[i, 0]).all() and (got["blocks"][i]["dy"] == shifts[i, 1]).all()
@@ -91,9 +88,8 @@ def test_c2_vga_8x8_bit_exact(aof, orc, synth, gpu_device, noise, brightness):
     assert got["variant"] == "lane8"
     assert got["blocks"].shape == (5, 4661)
     check_against_oracle(aof, orc, p, prevs, curs, got)
-    strip = run_gpu(aof, p, prevs, curs, gpu_device, strips=True)
-    assert strip["variant"] == "tile8_lds"
-    check_against_oracle(aof, orc, p, prevs, curs, strip)
+    fused = run_gpu(aof, p, prevs, curs, gpu_device, fused_reduce=True)   # reduction inside the search launch
+    check_against_oracle(aof, orc, p, prevs, curs, fused)
 
 
 def test_c2_generic_kernel_agrees(aof, orc, synth, gpu_device):
@@ -205,28 +201,35 @@ def test_small_pairs_in_one_launch(aof, orc, synth, gpu_device, kw, w, h, n):
 
 
 @pytest.mark.parametrize("levels", [1, 2])
-def test_every_mode_stays_inside_the_workspace(aof, orc, synth, gpu_device, levels):
-    """A published sparse grid whose step comes out as 8 from origin 5 has the shape of a dense grid:
-    the strip kernel takes it in the ..._STRIPS modes and votes into per-strip histograms, which the
-    workspace layout must have reserved (it once sized them by grid mode and the kernel wrote 880
-    bytes past the end).  Guard bytes behind the workspace, every search mode and kernel choice."""
+@pytest.mark.parametrize("geometry", ["sparse_step8", "dense_vga_chunked"])
+def test_every_mode_stays_inside_the_workspace(aof, orc, synth, gpu_device, levels, geometry):
+    """Guard bytes behind the workspace, every search mode and kernel choice: a published sparse grid
+    whose step comes out as 8 from origin 5 (the shape of a dense grid -- a strip kernel that has since
+    been removed once took it and wrote 880 bytes past a layout sized by grid mode), and a grid large
+    enough for the two-step reduction, whose per-chunk histograms live in the workspace."""
     import torch
-    p = aof.px4flow_params(64, 64, num_blocks=6, pyramid_levels=levels, min_valid=0)
-    assert aof.grid(p, 0)[:4] == (5, 5, 8, 8)
+    if geometry == "sparse_step8":
+        p = aof.px4flow_params(64, 64, num_blocks=6, pyramid_levels=levels, min_valid=0)
+        assert aof.grid(p, 0)[:4] == (5, 5, 8, 8)
+        W, H, reach = 64, 64, 4
+    else:
+        W, H, reach = 1024, 768, 4      # 127 x 95 = 12 065 blocks > 8 192: k_reduce_chunk + k_reduce
+        p = aof.default_params(W, H, pyramid_levels=levels, min_valid=0)
+        assert aof.workspace_layout(p, 1).total_bytes > aof.workspace_layout(p, 1).l0_hist
     n = 2
-    prevs, curs, _ = synth.make_batch(64, 64, n, 4, 4242, noise=2)
+    prevs, curs, _ = synth.make_batch(W, H, n, reach, 4242, noise=2)
     tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
     L = aof.workspace_layout(p, n)
-    assert L.total_bytes > L.l0_hist, "the strips' histograms need room in the layout"
     po = orc.params_from(p)
     refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
-    for mode in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_EXHAUSTIVE_STRIPS, aof.SEARCH_PRUNED, aof.SEARCH_PRUNED_STRIPS,
-                 "generic", "split"):
+    for mode in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED, "generic", "split", "fused_reduce"):
         eng = aof.FlowEngine(p, 0)
         if mode == "generic":
             eng.force_generic(True)
         elif mode == "split":
             eng.set_split_coarse(True)
+        elif mode == "fused_reduce":
+            eng.set_reduce_fusion(True)
         else:
             eng.set_search_mode(mode)
         big = torch.full((L.total_bytes + 8192,), 0xAB, dtype=torch.uint8, device=gpu_device)
@@ -237,6 +240,7 @@ def test_every_mode_stays_inside_the_workspace(aof, orc, synth, gpu_device, leve
         gb, gf = aof.blocks_view(blocks), aof.flows_view(flows)
         for i in range(n):
             assert gb[i].tobytes() == refs[i]["blocks"].tobytes() and gf[i].tobytes() == refs[i]["flow"].tobytes(), (mode, i)
+        eng.close()
 
 
 def test_c5_1280x960_16x16_search8(aof, orc, synth, gpu_device):
@@ -318,13 +322,11 @@ def test_c4_full_batch_of_1024_pairs_through_the_shard_and_gather_path(aof, orc,
     assert aof.flows_view(flows).tobytes() == f.tobytes()
 
 
-@pytest.mark.parametrize("sub", [1, 3, 4])
 @pytest.mark.parametrize("kw", [dict(pyramid_levels=2, mean_subtract=1), dict(pyramid_levels=2, subpixel=1),
                                 dict(pyramid_levels=2, mean_subtract=1, tile=16, search=8, value_threshold=12000)])
-def test_pipelined_sub_batches_give_the_same_records(aof, orc, synth, gpu_device, sub, kw):
-    """Two-level batches run as pipelined sub-batches on two streams (aof_set_pipeline): the
-    records must not depend on the sub-batch size (ragged last sub-batch included), eagerly
-    and when the whole call is captured into a hipGraph and replayed."""
+def test_two_level_batch_replays_from_a_graph(aof, orc, synth, gpu_device, kw):
+    """A two-level batch call allocates nothing and never synchronises: captured into a hipGraph and
+    replayed on NEW frames in the same buffers it returns the oracle's records every time."""
     import torch
     W, H = (192, 160) if kw.get("tile") == 16 else (128, 96)
     p = aof.default_params(W, H, **kw)
@@ -333,11 +335,9 @@ def test_pipelined_sub_batches_give_the_same_records(aof, orc, synth, gpu_device
     prev = torch.from_numpy(hp).to(gpu_device)
     cur = torch.from_numpy(hc).to(gpu_device)
     eng = aof.FlowEngine(p, 0)
-    eng.set_pipeline(0)
     b0, f0, _ = eng.flow_batch(prev, cur)
     torch.cuda.synchronize()
     check_against_oracle(aof, orc, p, hp, hc, dict(blocks=aof.blocks_view(b0), flows=aof.flows_view(f0)))
-    eng.set_pipeline(sub)
     blocks = torch.zeros_like(b0)
     flows = torch.zeros_like(f0)
     ws = torch.zeros(aof.workspace_layout(p, n).total_bytes, dtype=torch.uint8, device=gpu_device)
@@ -521,15 +521,15 @@ def test_reduction_inside_the_search_launch_equals_k3(aof, orc, synth, gpu_devic
 # ---- shapes, options and edge cases ---------------------------------------------
 
 SHAPES = [
-    dict(width=128, height=96),                                   # tile8 fast path, several strips
+    dict(width=128, height=96),                                   # dense, rows a multiple of 16 bytes
     dict(width=136, height=72),                                   # width % 16 != 0 -> lane8
     dict(width=188, height=120, pyramid_levels=2, mean_subtract=1),  # lane8 with predictor + equalisation
     dict(width=188, height=120, subpixel=1),                      # lane8 + refine pass
     dict(width=96, height=81),                                    # odd height, 1 level
-    dict(width=160, height=128, pyramid_levels=2),                # shifted tile8 path
+    dict(width=160, height=128, pyramid_levels=2),                # level 0 under a predictor
     dict(width=160, height=128, pyramid_levels=2, mean_subtract=1, hist_filter=0),
     dict(width=100, height=90, mean_subtract=1),                  # sums via the scalar K1 path
-    dict(width=128, height=96, subpixel=1),                       # dense + half-pixel: tile8 + refine pass
+    dict(width=128, height=96, subpixel=1),                       # dense + half-pixel
     dict(width=160, height=128, subpixel=1, pyramid_levels=2, mean_subtract=1),
     dict(width=160, height=130, subpixel=1, pyramid_levels=2),    # shifted path, odd level-1 height
     dict(width=160, height=130, subpixel=1),                      # H = 8k+18: the ring's last row is the frame's last row
@@ -573,11 +573,11 @@ def test_shapes_and_options(aof, orc, synth, gpu_device, case):
                          subdirs=sub.cpu().numpy() if sub is not None else None)
 
 
-@pytest.mark.parametrize("mode", ["exhaustive", "strips", "pruned", "pruned_strips", "generic"])
+@pytest.mark.parametrize("mode", ["exhaustive", "fused_reduce", "pruned", "generic"])
 @pytest.mark.parametrize("kw", [dict(), dict(pyramid_levels=2, mean_subtract=1)])
 def test_vga_dense_half_pixel(aof, orc, synth, gpu_device, mode, kw):
-    """Dense grid with half-pixel refinement (origin S+1): the LDS-tiled integer search on the
-    moved origin plus the refinement pass must equal the oracle, every direction exercised."""
+    """Dense grid with half-pixel refinement (origin S+1): the integer search on the moved origin
+    plus the refinement in the same lane must equal the oracle, every direction exercised."""
     import torch
     p = aof.default_params(640, 480, subpixel=1, **kw)
     n = 10
@@ -591,12 +591,8 @@ def test_vga_dense_half_pixel(aof, orc, synth, gpu_device, mode, kw):
     elif mode == "pruned":
         eng.set_search_mode(aof.SEARCH_PRUNED)
         assert eng.variant == "lane8"
-    elif mode == "pruned_strips":
-        eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
-        assert eng.variant == "tile8_lds"
-    elif mode == "strips":
-        eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
-        assert eng.variant == "tile8_lds"
+    elif mode == "fused_reduce":
+        eng.set_reduce_fusion(True)
     tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
     sub = torch.full((n, eng.nblocks(0)), 99, dtype=torch.uint8, device=gpu_device)
     blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
@@ -613,7 +609,7 @@ SMALL = [
     (dict(px4=1, num_blocks=8), 96, 80),
     (dict(subpixel=1), 128, 128),                               # the reference application's image size, dense
     (dict(subpixel=1, mean_subtract=1), 128, 96),
-    (dict(), 136, 72),                                          # rows of 136 bytes: no strip kernel
+    (dict(), 136, 72),                                          # rows of 136 bytes
     (dict(mean_subtract=1, feature_threshold=0, value_threshold=70000), 100, 64),
 ]
 
@@ -645,8 +641,8 @@ def test_small_frames(aof, orc, synth, gpu_device, case):
 
 
 CANARY = [
-    dict(width=640, height=480),                                           # tile8, DMA staging
-    dict(width=640, height=480, subpixel=1),                               # tile8 + in-kernel refinement
+    dict(width=640, height=480),                                           # flat lane8, K3 / in-launch reduction
+    dict(width=640, height=480, subpixel=1),                               # flat lane8 + refinement in the lane
     dict(width=160, height=130, pyramid_levels=2, mean_subtract=1, subpixel=1),
     dict(width=320, height=240, tile=16, search=8, value_threshold=12000, subpixel=1),  # tile16 + K2b
     dict(px4=1, width=64, height=64),                                      # grouped lane8
@@ -682,13 +678,9 @@ def test_no_writes_outside_the_output_buffers(aof, synth, gpu_device, case):
         gaps.append((off + v, end + guard))
         off = end + guard
     assert views["ws"].data_ptr() % 256 == 0 and views["blocks"].data_ptr() % 4 == 0
-    for mode in ("default", "strips", "pruned", "pruned_strips"):
-        if mode == "pruned":
-            eng.set_search_mode(aof.SEARCH_PRUNED)
-        elif mode == "pruned_strips":
-            eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
-        elif mode == "strips":
-            eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
+    for mode in ("default", "fused_reduce", "pruned"):
+        eng.set_reduce_fusion(mode == "fused_reduce")
+        eng.set_search_mode(aof.SEARCH_PRUNED if mode == "pruned" else aof.SEARCH_EXHAUSTIVE)
         eng.flow_batch(tp, tc, blocks=views["blocks"].view(torch.int32).view(n, nb),
                        subdirs=views["subdirs"].view(n, nb) if p.subpixel else None,
                        flows=views["flows"].view(n, 16), workspace=views["ws"])

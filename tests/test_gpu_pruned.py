@@ -1,4 +1,4 @@
-"""AOF_SEARCH_PRUNED (exact partial-distortion elimination in the tile8 kernel) must return
+"""AOF_SEARCH_PRUNED (exact partial-distortion elimination in the lane8 and tile16 kernels) must return
 the same bytes as the exhaustive search and as the oracle on every kind of input: clean
 translations (maximal pruning), noise (no pruning), periodic textures and identical frames
 (ties everywhere -- the tie-break must survive the changed visiting order), flat regions
@@ -12,8 +12,6 @@ pytestmark = pytest.mark.gpu
 def run(aof, p, prevs, curs, device, mode, hint_fill=None, reps=1):
     import torch
     eng = aof.FlowEngine(p, 0)
-    # the strip kernel serves PRUNED and EXHAUSTIVE_STRIPS; plain EXHAUSTIVE requests become the
-    # latter here so that both code paths of that kernel are compared
     eng.set_search_mode(mode)
     tp, tc = torch.from_numpy(prevs).to(device), torch.from_numpy(curs).to(device)
     n = prevs.shape[0]
@@ -30,12 +28,9 @@ def run(aof, p, prevs, curs, device, mode, hint_fill=None, reps=1):
 def both_modes_match_oracle(aof, orc, p, prevs, curs, device):
     po = orc.params_from(p)
     refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(prevs.shape[0])]
-    # every search mode: default (lane-per-block), pruned in both kernels, exhaustive strips
-    for mode, hint, reps in ((aof.SEARCH_EXHAUSTIVE, None, 1), (aof.SEARCH_EXHAUSTIVE_STRIPS, None, 1),
-                             (aof.SEARCH_PRUNED, None, 1), (aof.SEARCH_PRUNED, 0, 2),
-                             (aof.SEARCH_PRUNED_STRIPS, None, 1), (aof.SEARCH_PRUNED_STRIPS, 0, 1),
-                             (aof.SEARCH_PRUNED_STRIPS, 8, 2), (aof.SEARCH_PRUNED_STRIPS, -12345, 1),
-                             (aof.SEARCH_PRUNED_STRIPS, 77, 3)):
+    # both search modes; the workspace may hold anything on entry, launches may repeat
+    for mode, hint, reps in ((aof.SEARCH_EXHAUSTIVE, None, 1), (aof.SEARCH_PRUNED, None, 1), (aof.SEARCH_PRUNED, 0, 2),
+                             (aof.SEARCH_PRUNED, 8, 2), (aof.SEARCH_PRUNED, -12345, 1), (aof.SEARCH_PRUNED, 77, 3)):
         b, f = run(aof, p, prevs, curs, device, mode, hint, reps)
         for i, r in enumerate(refs):
             assert b[i].tobytes() == r["blocks"].tobytes(), (mode, hint, i)

@@ -1,4 +1,4 @@
-"""ASan + UBSan over the product's host-only logic (parameter validation, grids, strip plans,
+"""ASan + UBSan over the product's host-only logic (parameter validation, grids, reduction chunks,
 workspace layout, MAVLink packer), 20 000 random parameter sets including invalid ones."""
 import os
 import subprocess

@@ -1,7 +1,9 @@
 // coarse_lab -- phase timing of the fused coarse kernel (not part of the product).
-// Builds k_coarse.hip with -DAOF_LAB (in-kernel s_memrealtime stamps at the phase boundaries) and
-// prints the median duration of every phase over all workgroups, next to the kernel's wall time.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAOF_LAB -Iinclude -Iaero-optical-flow_amd/csrc \
+// Builds k_coarse.hip with the lab definitions of its instrumentation points (tools/coarse_lab_hooks.hpp:
+// in-kernel s_memrealtime stamps at the phase boundaries) and prints the median duration of every phase
+// over all workgroups, next to the kernel's wall time.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAOF_LAB_HOOKS='"../../tools/coarse_lab_hooks.hpp"' \
+//         -Iinclude -Iaero-optical-flow_amd/csrc \
 //         tools/coarse_lab.hip aero-optical-flow_amd/csrc/aof_params.cpp -o tools/coarse_lab
 #include <hip/hip_runtime.h>
 #include <algorithm>

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long differential fuzz on a GPU box (not part of the test suite): random geometry, options
-and image statistics; default, strip-kernel, pruned, generic and separate-kernel device paths against the CPU oracle.
+and image statistics; default, in-launch reduction, pruned, generic and separate-kernel device paths against the CPU oracle.
     python tools/fuzz_gpu.py [n_cases] [first_seed]            random configurations, two pairs per call
     python tools/fuzz_gpu.py [n_cases] [first_seed] many       the persistent coarse kernel: hundreds of pairs per call"""
 import importlib
@@ -170,7 +170,7 @@ def main():
         small = small_eligible(p, aof.grid(p, 0), aof.grid(p, 1) if p.pyramid_levels == 2 else None)
         refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
         tp, tc = torch.from_numpy(prevs).to(dev), torch.from_numpy(curs).to(dev)
-        for mode in ("exhaustive", "strips", "pruned", "pruned_strips", "generic", "split"):
+        for mode in ("exhaustive", "fused_reduce", "pruned", "generic", "split"):
             if mode == "split" and p.pyramid_levels != 2 and not small:
                 continue   # (the separate kernels instead of k_coarse / k_flow_small)
             eng = aof.FlowEngine(p, 0)
@@ -180,10 +180,8 @@ def main():
                 eng.force_generic(True)
             elif mode == "pruned":
                 eng.set_search_mode(aof.SEARCH_PRUNED)
-            elif mode == "strips":
-                eng.set_search_mode(aof.SEARCH_EXHAUSTIVE_STRIPS)
-            elif mode == "pruned_strips":
-                eng.set_search_mode(aof.SEARCH_PRUNED_STRIPS)
+            elif mode == "fused_reduce":
+                eng.set_reduce_fusion(True)
             nb = eng.nblocks(0)
             # every output carved out of one arena with guard zones in between: a kernel that writes
             # outside its buffers is caught even when the records it returns are right
