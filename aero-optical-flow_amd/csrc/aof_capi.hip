@@ -3,9 +3,9 @@
 //
 // Launch sequence of aof_flow_batch_device (DESIGN.md "Kernels"):
 //   1 level :                      K2 search(L0) -> K3 reduce
-//   + mean  : memset sums -> K1 -> K2 search(L0) -> K3 reduce
+//   + mean  : K1 (zeroes and fills the pixel sums) -> K2 search(L0) -> K3 reduce
 //   2 levels: k_coarse (sums, pyramid, level-1 search and predictor of a pair in one workgroup)
-//             or [memset] -> K1 -> K2 search(L1) -> K3 reduce(L1: predictor),
+//             or K1 -> K2 search(L1) -> K3 reduce(L1: predictor),
 //             then K2 search(L0, shifted by predictor) -> K3 reduce
 //   small pairs (<= 128 per call, frames that fit LDS): k_flow_small, everything in one launch
 // Everything is enqueued on the caller's stream; nothing allocates or
@@ -274,7 +274,6 @@ int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, h
             return 0;
         }
     }
-    if (eq) HIP_TRY(ctx, hipMemsetAsync(sums, 0, (size_t)n * 4 * sizeof(uint32_t), s));   // K1 adds with integer atomics
     PyramidArgs a;
     a.prev = v.prev + first * v.stride; a.cur = v.cur + first * v.stride; a.pair_stride = v.stride;
     a.w = p.width; a.h = p.height;

@@ -137,7 +137,8 @@ struct PyramidArgs {
 
 // Kernel launchers (one per .hip file).  All enqueue on `stream` and return the
 // hipError_t of the launch as int (0 = ok).
-int launch_pyramid(const PyramidArgs &a, void *stream);
+int launch_pyramid(const PyramidArgs &a, void *stream);   // zeroes a.sums first
+int launch_zero_words(uint32_t *words, int64_t count, void *stream);   // (a kernel: replays correctly from a hipGraph)
 bool coarse_fused_supported(const CoarseArgs &a);
 int launch_coarse_fused(const CoarseArgs &a, void *stream);
 int launch_search_generic(const SearchArgs &a, void *stream);

@@ -135,8 +135,8 @@ int launch_ingest(const aof_ingest_params &p, const uint8_t *camera, int64_t cam
     if (n_frames == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hist) {
-        hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_frames * AOF_EXPOSURE_BINS * sizeof(uint32_t), s);
-        if (e != hipSuccess) return (int)e;
+        const int rc = launch_zero_words(hist, n_frames * AOF_EXPOSURE_BINS, stream);
+        if (rc) return rc;
     }
     const int nstrips = (p.crop_height + kRowsPerBlock - 1) / kRowsPerBlock;
     const int vec = (p.crop_width % 16 == 0) && (!cropped || (reinterpret_cast<uintptr_t>(cropped) % 16 == 0 &&

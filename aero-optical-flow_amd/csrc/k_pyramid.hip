@@ -106,12 +106,35 @@ __global__ __launch_bounds__(kThreads) void k_pyramid_scalar(PyramidArgs a, int 
     }
 }
 
+// Accumulators that integer atomics add to start from zero.  Zeroed by a kernel of our own, not by
+// hipMemsetAsync: captured into a hipGraph, the memset node of ROCm 7.2 left garbage in the 16 bytes of
+// pixel sums per pair when the graph was replayed (tests/test_gpu_parity.py::test_two_level_batch_
+// replays_from_a_graph found it) -- a kernel node replays like every other kernel here.
+__global__ __launch_bounds__(kThreads) void k_zero_words(uint32_t *words, int64_t count)
+{
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < count) words[i] = 0;
+}
+
 }  // namespace
+
+int launch_zero_words(uint32_t *words, int64_t count, void *stream)
+{
+    if (count <= 0) return 0;
+    const int64_t wgs = (count + kThreads - 1) / kThreads;
+    if (wgs > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_zero_words, dim3((uint32_t)wgs), dim3(kThreads), 0, static_cast<hipStream_t>(stream), words, count);
+    return (int)hipGetLastError();
+}
 
 int launch_pyramid(const PyramidArgs &a, void *stream)
 {
     if (a.n_pairs == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.sums) {
+        const int rc = launch_zero_words(a.sums, a.n_pairs * 4, stream);
+        if (rc) return rc;
+    }
     const bool vec = (a.w % 16 == 0) && (a.h % 2 == 0) && (a.pair_stride % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(a.prev) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(a.cur) % 16 == 0);
