@@ -215,7 +215,11 @@ __device__ __forceinline__ void wave_vote_agent(uint32_t *hist, int bin, bool ac
 }
 
 // Search side, called by ALL 64 lanes of a wave.  `member`: the lane's block belongs to `pair`
-// (wave-uniform pair); `ok`: it votes, for bins (bin_x, bin_y).
+// (wave-uniform pair); `ok`: it votes, for bins (bin_x, bin_y).  Written so that everything a wave
+// under ONE motion needs stays in scalar registers (ballots, the leader's key through v_readlane, the
+// counts through s_bcnt1) and one lane issues the three adds: the search kernel is VALU-issue-bound, and
+// every vector instruction here is paid for at the full rate (a first version cost 120 VALU per wave,
+// 6 % of the search).
 __device__ __forceinline__ void vote_and_arrive(const VoteMem &vm, int range, uint32_t pair, bool member, bool ok,
                                                 int bin_x, int bin_y)
 {
@@ -225,25 +229,32 @@ __device__ __forceinline__ void vote_and_arrive(const VoteMem &vm, int range, ui
     uint32_t *rec = vm.base + (size_t)pair * vm.stride, *hist_x = rec + 2, *hist_y = rec + 2 + n;
     ok = ok && member;
     const unsigned long long voters = __ballot(ok);
+    const int head = __ffsll((long long)members) - 1;
+    const unsigned long long arrival = ((unsigned long long)__popcll(members) << 32) | (unsigned long long)__popcll(voters);
+    bool one_motion = true;
+    int k = 0;
     if (voters) {
         const int key = bin_x | (bin_y << 8);
-        const int first = __ffsll((long long)voters) - 1;
-        const int k = __shfl(key, first, 64);
-        if ((__ballot(ok && key == k) & voters) == voters) {   // one motion in the whole wave: two adds
-            if (lane == first) {
+        k = __builtin_amdgcn_readlane(key, __ffsll((long long)voters) - 1);   // scalar
+        one_motion = (__ballot(ok && key == k) & voters) == voters;
+    }
+    if (one_motion) {   // (wave-uniform) two adds for the votes, one for the arrival, all from one lane
+        if (lane == head) {
+            if (voters) {
                 const uint32_t c = (uint32_t)__popcll(voters);
                 vote_add_agent(&hist_x[k & 0xFF], c);
                 vote_add_agent(&hist_y[k >> 8], c);
             }
-        } else {
-            wave_vote_agent(hist_x, bin_x, ok);
-            wave_vote_agent(hist_y, bin_y, ok);
+            (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(rec), arrival, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
         }
+        return;
     }
-    if (lane == __ffsll((long long)members) - 1)
-        (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(rec),
-                                     ((unsigned long long)__popcll(members) << 32) | (unsigned long long)__popcll(voters),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wave_vote_agent(hist_x, bin_x, ok);
+    wave_vote_agent(hist_y, bin_y, ok);
+    if (lane == head)
+        (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(rec), arrival, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Finaliser side: ONE WAVE per pair (all 64 lanes), n <= 62.  Gives up after `deadline_ticks` of the

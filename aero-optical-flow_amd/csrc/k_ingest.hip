@@ -6,14 +6,18 @@
 // over the centred 128x128 region of the cropped image (mainloop.cpp:203-214).
 //
 // HBM-bound byte mover: only the crop window of each sensor frame is read (16 B per lane,
-// rows of the window are contiguous runs of crop_w bytes) and written once.  The bin of
-// a grey value is floor(v*10/255) -- equal to cv::calcHist's double arithmetic for all
-// 256 values (tests/test_ingest.py) -- with v = 255 outside the half-open range.  A lane
-// counts the 16 pixels of its piece in two registers of packed 12-bit fields (5 bins
-// each; a whole wave's 1024 pixels still fit a field), the wave adds them with a
-// butterfly of shuffles, and one lane per wave adds the ten sums to the workgroup's LDS
-// histogram; a single integer global atomic per bin and workgroup publishes it
-// (order-independent).
+// rows of the window are contiguous runs of crop_w bytes) and written once -- a plain copy of exactly
+// these 128-byte row pieces at a 640-byte stride runs at the device's dense copy rate (5.4-6.0 TB/s,
+// tools/ubench_rowcopy.hip, profiles/r03_ubench_rowcopy.txt), so the access pattern is no limit; the
+// histogram arithmetic is what the kernel has to hide under it.  The bin of a grey value is
+// floor(v*10/255) -- equal to cv::calcHist's double arithmetic for all 256 values
+// (tests/test_ingest.py) -- with v = 255 outside the half-open range.  Per pixel that is ONE LDS read:
+// a 256-entry table per workgroup gives the pixel's one-hot increment, two words of five 6-bit counters
+// (bins 0..4 / 5..9; v = 255 adds nothing; 16-byte entries for 8-bit counters measured 1.4x slower), which
+// a lane adds up over three pieces and then widens into 16-bit counters; at the end the wave adds those
+// with ONE butterfly of shuffles and lanes 0..9 add a bin each to the workgroup's LDS histogram.  A workgroup that owns its frame's whole crop
+// (crops of up to 128 rows) stores the ten totals; taller crops take several workgroups per frame, which
+// add to a zeroed histogram with one integer global atomic per bin (order-independent).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 
@@ -22,30 +26,50 @@ namespace aof {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kRowsPerBlock = 128;
-constexpr int kField = 12;  // bits per packed counter
+#ifndef AOF_INGEST_ROWS
+#define AOF_INGEST_ROWS 128
+#endif
+constexpr int kRowsPerBlock = AOF_INGEST_ROWS;
+constexpr int kLaneField = 6;      // bits per counter of a lane's table sums: <= 3 pieces x 16 pixels = 48 < 64
+constexpr int kLanePieces = 3;     // pieces between two widenings
+constexpr int kWavePieces = 63;    // pieces per lane between two wave sums: 63 x 16 x 64 lanes = 64 512 < 65 536
 
 __device__ __forceinline__ int exposure_bin(uint32_t v) { return (int)((v * 10u) / 255u); }  // 10 => dropped
 
-// Wave-wide sum of the packed counters (callers flush after at most 3 pieces per lane, so
-// a field holds <= 3 x 16 x 64 = 3072 < 2^12), then one lane adds the ten totals to the
-// workgroup histogram.  Must be called by every lane of the wave.
-__device__ __forceinline__ void flush_counts(uint32_t *s_hist, u64 lo, u64 hi)
+// A lane's ten counters as 16-bit fields, two per word (bins 2k and 2k+1 in word k).
+struct LaneCounts { uint32_t w[5]; };
+
+// Adds the two table-sum words (five 6-bit counters each: bins 0..4 / 5..9) to the lane's 16-bit counters.
+__device__ __forceinline__ void widen_add(LaneCounts &n, uint32_t lo, uint32_t hi)
+{
+    constexpr uint32_t m = (1u << kLaneField) - 1;
+    n.w[0] += (lo & m) | (((lo >> kLaneField) & m) << 16);
+    n.w[1] += ((lo >> (2 * kLaneField)) & m) | (((lo >> (3 * kLaneField)) & m) << 16);
+    n.w[2] += ((lo >> (4 * kLaneField)) & m) | ((hi & m) << 16);
+    n.w[3] += ((hi >> kLaneField) & m) | (((hi >> (2 * kLaneField)) & m) << 16);
+    n.w[4] += ((hi >> (3 * kLaneField)) & m) | (((hi >> (4 * kLaneField)) & m) << 16);
+}
+
+// Wave-wide sum of the lanes' counters (plain word adds: no field can overflow, see kWavePieces); every
+// lane ends up with the totals, and lanes 0..9 add one bin each to the workgroup histogram.  Must be
+// called by every lane of the wave.
+__device__ __forceinline__ void flush_counts(uint32_t *s_hist, LaneCounts &n)
 {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
-        lo += ((u64)(uint32_t)__shfl_xor((int)(lo >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)lo, o, 64);
-        hi += ((u64)(uint32_t)__shfl_xor((int)(hi >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)hi, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int b = 0; b < 5; b++) {
-            const uint32_t c0 = (uint32_t)(lo >> (kField * b)) & ((1u << kField) - 1);
-            const uint32_t c1 = (uint32_t)(hi >> (kField * b)) & ((1u << kField) - 1);
-            if (c0) atomicAdd(&s_hist[b], c0);
-            if (c1) atomicAdd(&s_hist[b + 5], c1);
-        }
+        for (int k = 0; k < 5; k++) n.w[k] += (uint32_t)__shfl_xor((int)n.w[k], o, 64);
     }
+    const int lane = (int)(threadIdx.x & 63);
+    if (lane < AOF_EXPOSURE_BINS) {
+        uint32_t word = n.w[0];
+#pragma unroll
+        for (int k = 1; k < 5; k++) word = (lane >> 1) == k ? n.w[k] : word;
+        const uint32_t c = (lane & 1) ? word >> 16 : word & 0xFFFFu;
+        if (c) atomicAdd(&s_hist[lane], c);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) n.w[k] = 0;
 }
 
 __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const uint8_t *camera,
@@ -54,12 +78,18 @@ __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const 
                                                      int vec)
 {
     __shared__ uint32_t s_hist[AOF_EXPOSURE_BINS];
+    __shared__ uint2 s_onehot[256];   // grey value -> one-hot increment of a lane's table sums (bins 0..4, bins 5..9)
     const int strip = blockIdx.x % nstrips;
     const int64_t frame = blockIdx.x / nstrips;
     const int tid = threadIdx.x;
     if (tid < AOF_EXPOSURE_BINS) s_hist[tid] = 0;
+    if (hist) {   // kThreads == 256: one table entry per lane
+        const int b = exposure_bin((uint32_t)tid);   // 10 for v = 255: outside cv::calcHist's range, counts nowhere
+        s_onehot[tid] = make_uint2(b < 5 ? 1u << (kLaneField * b) : 0u, (b >= 5 && b < 10) ? 1u << (kLaneField * (b - 5)) : 0u);
+    }
     __syncthreads();
-    u64 cnt_lo = 0, cnt_hi = 0;  // bins 0..4 / 5..9, kField bits each
+    LaneCounts cnt = {{0u, 0u, 0u, 0u, 0u}};
+    uint32_t sum_lo = 0, sum_hi = 0;  // table sums since the last widening
 
     const int x0 = p.camera_width / 2 - p.crop_width / 2, y0 = p.camera_height / 2 - p.crop_height / 2;
     int mx0 = p.crop_width / 2 - AOF_EXPOSURE_MASK_SIZE / 2, my0 = p.crop_height / 2 - AOF_EXPOSURE_MASK_SIZE / 2;
@@ -96,20 +126,28 @@ __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const 
                 if (active && dst) *reinterpret_cast<uint4 *>(dst + (int64_t)y * p.crop_width + x) = v[u];
                 if (active && hist && y >= my0 && y < my1 && x + 16 > mx0 && x < mx1) {
                     const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    if (x >= mx0 && x + 16 <= mx1) {   // the whole piece lies inside the mask: one table read per pixel
 #pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        const bool in = x + k >= mx0 && x + k < mx1;
-                        const int b = exposure_bin((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-                        // b == 10 (v == 255) is outside cv::calcHist's range: shifted out of both words
-                        cnt_lo += (in && b < 5) ? 1ull << (kField * b) : 0ull;
-                        cnt_hi += (in && b >= 5 && b < 10) ? 1ull << (kField * (b - 5)) : 0ull;
+                        for (int k = 0; k < 16; k++) {
+                            const uint2 e = s_onehot[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+                            sum_lo += e.x; sum_hi += e.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            if (x + k < mx0 || x + k >= mx1) continue;
+                            const uint2 e = s_onehot[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+                            sum_lo += e.x; sum_hi += e.y;
+                        }
                     }
                 }
-                // 3 pieces x 16 pixels x 64 lanes = 3072 < 4096: flush before a field can overflow
-                if (hist && round % 3 == 2) { flush_counts(s_hist, cnt_lo, cnt_hi); cnt_lo = cnt_hi = 0; }
+                // (uniform trip counts) the 6-bit table sums hold three pieces, the 16-bit counters of a
+                // wave sum 63 pieces per lane
+                if (hist && round % kLanePieces == kLanePieces - 1) { widen_add(cnt, sum_lo, sum_hi); sum_lo = sum_hi = 0; }
+                if (hist && round % kWavePieces == kWavePieces - 1) flush_counts(s_hist, cnt);
             }
         }
-        if (hist) flush_counts(s_hist, cnt_lo, cnt_hi);
+        if (hist) { widen_add(cnt, sum_lo, sum_hi); flush_counts(s_hist, cnt); }
     } else {
         const int items = (row_end - row_begin) * p.crop_width;
         for (int it = tid; it < items; it += kThreads) {
@@ -124,7 +162,10 @@ __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const 
     }
     if (!hist) return;
     __syncthreads();
-    if (tid < AOF_EXPOSURE_BINS && s_hist[tid]) atomicAdd(&hist[frame * AOF_EXPOSURE_BINS + tid], s_hist[tid]);
+    if (tid < AOF_EXPOSURE_BINS) {
+        if (nstrips == 1) hist[frame * AOF_EXPOSURE_BINS + tid] = s_hist[tid];   // the workgroup owns the frame: no zeroing pass, no atomic
+        else if (s_hist[tid]) atomicAdd(&hist[frame * AOF_EXPOSURE_BINS + tid], s_hist[tid]);
+    }
 }
 
 }  // namespace
@@ -134,11 +175,11 @@ int launch_ingest(const aof_ingest_params &p, const uint8_t *camera, int64_t cam
 {
     if (n_frames == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hist) {
+    const int nstrips = (p.crop_height + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (hist && nstrips > 1) {   // several workgroups add to a frame's histogram
         const int rc = launch_zero_words(hist, n_frames * AOF_EXPOSURE_BINS, stream);
         if (rc) return rc;
     }
-    const int nstrips = (p.crop_height + kRowsPerBlock - 1) / kRowsPerBlock;
     const int vec = (p.crop_width % 16 == 0) && (!cropped || (reinterpret_cast<uintptr_t>(cropped) % 16 == 0 &&
                                                                 cropped_stride % 16 == 0));
     hipLaunchKernelGGL(k_ingest, dim3((uint32_t)(n_frames * nstrips)), dim3(kThreads), 0, s, p, camera,

@@ -72,8 +72,13 @@ __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t item
             asm volatile("" : "+v"(lane_id));
             const uint32_t item2 = item0 + lane_id;
             const bool live2 = item2 < items;
-            const uint32_t pair2 = live2 ? fast_div(item2, a.div_nb) : 0u;
-            const bool ok = live2 && (uint32_t)rec.sad < (uint32_t)a.value_threshold;   // skipped = 0xFFFF
+            // the wave's first pair and where the next one begins, in scalar registers (a wave covers at
+            // most two pairs; lane 0 is live or the whole wave is past the end)
+            const uint32_t first_item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item2);
+            const uint32_t lead = fast_div(first_item, a.div_nb);
+            const uint32_t next_pair_at = (lead + 1) * nb;
+            const uint32_t rec32 = __builtin_bit_cast(uint32_t, rec);
+            const bool ok = live2 && (rec32 >> 16) < (uint32_t)a.value_threshold;   // skipped = 0xFFFF
             int hx = 0, hy = 0;
             if (SUBPIXEL) {
                 hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
@@ -81,9 +86,9 @@ __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t item
             }
             const int centre = 2 * a.hist_range + 1;
             const int bin_x = 2 * rec.dx + hx + centre, bin_y = 2 * rec.dy + hy + centre;
-            const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair2);   // lane 0 is live or the wave is empty
-            vote_and_arrive(*votes, a.hist_range, lead, live2 && pair2 == lead, ok, bin_x, bin_y);
-            vote_and_arrive(*votes, a.hist_range, lead + 1, live2 && pair2 != lead, ok, bin_x, bin_y);
+            vote_and_arrive(*votes, a.hist_range, lead, live2 && item2 < next_pair_at, ok, bin_x, bin_y);
+            if (first_item + 63 >= next_pair_at)   // (scalar) the wave reaches into the next pair
+                vote_and_arrive(*votes, a.hist_range, lead + 1, live2 && item2 >= next_pair_at, ok, bin_x, bin_y);
         }
     }
 }

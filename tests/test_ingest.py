@@ -66,7 +66,8 @@ def test_ingest_rejects_bad_geometry(aof):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cam,crop", [((320, 240), (128, 128)), ((640, 480), (128, 128)),
                                       ((160, 120), (64, 64)), ((322, 242), (100, 90)),
-                                      ((640, 480), (640, 480)), ((1280, 960), (256, 192))])
+                                      ((640, 480), (640, 480)), ((1280, 960), (256, 192)),
+                                      ((320, 240), (144, 136)), ((640, 480), (400, 128))])   # mask edges inside 16-byte pieces; 12.5 pieces per lane
 def test_gpu_ingest_parity(aof, orc, gpu_device, cam, crop):
     import torch
     rng = np.random.default_rng(cam[0] + crop[0])
