@@ -105,6 +105,7 @@ def _load():
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
         "aof_stream_reset": (C.c_int, [VP]),
         "aof_set_stream_graph": (C.c_int, [VP, C.c_int]),
+        "aof_set_stream_resident": (C.c_int, [VP, C.c_int]),
         "aof_ingest_batch_device": (C.c_int, [P(IngestParams), VP, I64, I64, VP, I64, VP, VP]),
         "aof_derotate_batch_device": (C.c_int, [P(DerotateParams), VP, VP, I64, VP, VP]),
         "aof_exposure_msv": (C.c_float, [VP]),
@@ -390,6 +391,14 @@ class FlowEngine:
         """Streaming entry point: replay a captured hipGraph per frame (default) or launch eagerly."""
         self._check(lib.aof_set_stream_graph(self._ctx, int(on)))
 
+    def set_stream_resident(self, on=True):
+        """Streaming entry point for small frames: a resident one-workgroup kernel serves the calls
+        through a mailbox in pinned memory instead of one launch per frame."""
+        self._check(lib.aof_set_stream_resident(self._ctx, int(on)))
+
+    def stream_resident_running(self) -> bool:
+        return lib.aof_set_stream_resident(self._ctx, -1) == 1
+
     def stream_graph_active(self) -> bool:
         return lib.aof_set_stream_graph(self._ctx, -1) == 1
 
@@ -437,6 +446,7 @@ def facade_lib():
         f.aof_facade_image_width.argtypes = [C.c_void_p]
         f.aof_facade_set_search_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int]
         f.aof_facade_pyramid_levels.argtypes = [C.c_void_p]
+        f.aof_facade_set_resident.argtypes = [C.c_void_p, C.c_int]
         f.aof_facade_image_height.argtypes = [C.c_void_p]
         f.aof_facade_last_error.restype = C.c_char_p
         f.aof_facade_last_error.argtypes = [C.c_void_p]
@@ -483,6 +493,10 @@ class _FacadeFlow:
 
     def getPyramidLevels(self):
         return facade_lib().aof_facade_pyramid_levels(self._h)
+
+    def setResidentKernel(self, on=True):
+        """Serve calcFlow() from a kernel that stays on the device (mailbox in pinned memory)."""
+        return bool(facade_lib().aof_facade_set_resident(self._h, int(bool(on))))
 
     def calcFlow(self, img, img_time_us):
         """Returns (quality, dt_us, flow_x_rad, flow_y_rad); the C++ out-parameters keep

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cerrno>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -56,6 +57,13 @@ struct aof_ctx {
     bool graph_disabled;        // capture failed once: stay on the plain path
     bool capturing;
     bool split_coarse;          // run K1 / level-1 search / level-1 reduce as separate kernels
+    // resident form of the per-call path (aof_set_stream_resident): one workgroup stays on the device
+    // and serves aof_stream_push_host through a mailbox in pinned memory
+    bool resident_on;
+    hipStream_t rstream;        // the resident kernel's own stream
+    ResidentBox *box;           // pinned, device-visible
+    uint32_t rseq;              // number of the last request posted
+    uint32_t rframe_req[2];     // request at which pinned frame b was posted as the newest frame, 0 = written otherwise
     // reduction inside the flat lane8 search (no K3 launch): the pairs' vote records, zero at rest
     uint32_t *d_votes;
     int64_t votes_pairs;        // records allocated
@@ -307,6 +315,69 @@ int enqueue_fine(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, hip
                          v.hist0 + (size_t)first * hist_bytes_per_pair(p, 0), AOF_K_SEARCH, AOF_K_REDUCE, s);
 }
 
+// Views of one batch inside the caller's buffers and workspace.
+BatchView batch_view(const aof_ctx *ctx, const aof_ws_layout &L, const uint8_t *d_prev, const uint8_t *d_cur,
+                     int64_t pair_stride, aof_block *d_blocks, uint8_t *d_subdirs, aof_flow *d_flows, void *d_workspace)
+{
+    const aof_params &p = ctx->params;
+    BatchView v;
+    uint8_t *ws = static_cast<uint8_t *>(d_workspace);
+    const bool two = p.pyramid_levels == 2, eq = p.mean_subtract != 0;
+    v.prev = d_prev; v.cur = d_cur; v.stride = pair_stride;
+    v.sums = eq ? reinterpret_cast<uint32_t *>(ws + L.sums) : nullptr;
+    v.l1_prev = two ? ws + L.l1_prev : nullptr;
+    v.l1_cur = two ? ws + L.l1_cur : nullptr;
+    v.blocks1 = reinterpret_cast<aof_block *>(ws + L.l1_blocks);
+    v.subdirs1 = p.subpixel ? ws + L.l1_subdirs : nullptr;
+    v.flows1 = reinterpret_cast<aof_flow *>(ws + L.l1_flows);
+    v.hist1 = ws + L.l1_hist;
+    v.blocks0 = d_blocks ? d_blocks : reinterpret_cast<aof_block *>(ws + L.l0_blocks);
+    v.subdirs0 = nullptr;
+    if (p.subpixel) v.subdirs0 = d_subdirs ? d_subdirs : ws + L.l0_subdirs;
+    v.flows = d_flows;
+    v.hist0 = ws + L.l0_hist;
+    return v;
+}
+
+// Small pairs (sparse grids, frames that fit LDS -- the reference's call shape): sums, pyramid, searches
+// and reductions of a pair in one launch, one workgroup per pair.  Large batches of such pairs keep the
+// separate kernels, whose grouped searches pack several pairs into a workgroup.  Fills *sm and says
+// whether the one-launch kernel serves the batch.
+bool small_args(const aof_ctx *ctx, const BatchView &v, int64_t n_pairs, SmallArgs *sm)
+{
+    const aof_params &p = ctx->params;
+    const bool two = p.pyramid_levels == 2;
+    if (ctx->force_generic || ctx->split_coarse || n_pairs > kSmallMaxPairs) return false;
+    sm->levels = two ? 2 : 1;
+    sm->l0 = search_args(ctx, 0, v.prev, v.cur, v.stride, v.blocks0, v.subdirs0, nullptr, v.sums, n_pairs);
+    sm->l1 = search_args(ctx, 1, v.l1_prev, v.l1_cur, (int64_t)(p.width / 2) * (p.height / 2), v.blocks1, v.subdirs1,
+                         nullptr, v.sums, n_pairs);
+    sm->t0 = flow_tail(ctx, 0, v.flows, two ? v.flows1 : nullptr);
+    sm->t1 = flow_tail(ctx, 1, v.flows1, nullptr);
+    sm->sums = v.sums;
+    return search_kind(ctx, sm->l0) == SK_LANE8_GROUP && (!two || search_kind(ctx, sm->l1) == SK_LANE8_GROUP) &&
+           flow_small_supported(*sm);
+}
+
+// ---- resident form of the per-call path ----
+constexpr uint64_t kResidentIdleTicks = 5000000;    // 50 ms of the 100 MHz counter without a request: the kernel leaves
+constexpr uint64_t kResidentLifeTicks = 20000000;   // 200 ms in total: nothing that waits for the device waits longer
+constexpr double kResidentHostTimeoutS = 0.25;      // the host gives up on a request and falls back to the graph path
+
+// Asks the resident kernel to leave and waits for it (bounded by the kernel's own deadlines).  Must run
+// before anything that frees or reallocates what the kernel reads, and before a change of kernel choice.
+void resident_stop(aof_ctx *ctx)
+{
+    if (!ctx->box || !ctx->rstream) return;
+    const unsigned long long word = __atomic_load_n(&ctx->box->word, __ATOMIC_ACQUIRE);
+    if (__atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE)) {
+        __atomic_store_n(&ctx->box->word, word | kResidentStopBit, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(ctx->rstream);
+    }
+    __atomic_store_n(&ctx->box->word, word & ~kResidentStopBit, __ATOMIC_RELEASE);
+    __atomic_store_n(&ctx->box->running, 0u, __ATOMIC_RELEASE);
+}
+
 }  // namespace
 
 extern "C" {
@@ -353,6 +424,9 @@ void aof_destroy(aof_ctx *ctx)
 {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
+    resident_stop(ctx);   // before anything it reads is freed
+    if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
+    if (ctx->box) (void)hipHostFree(ctx->box);
     if (ctx->ev) {
         for (int k = 0; k < AOF_K_COUNT; k++)
             for (int r = 0; r < AOF_PROFILE_RING; r++)
@@ -403,6 +477,7 @@ const char *aof_search_variant(const aof_ctx *ctx)
 int aof_set_force_generic(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
+    { DeviceGuard guard(ctx->device); resident_stop(ctx); }   // it runs the kernels chosen so far
     if ((on != 0) != ctx->force_generic)   // captured graphs hold the old kernels
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
@@ -413,6 +488,7 @@ int aof_set_force_generic(aof_ctx *ctx, int on)
 int aof_set_search_mode(aof_ctx *ctx, int mode)
 {
     if (!ctx || mode < AOF_SEARCH_EXHAUSTIVE || mode > AOF_SEARCH_PRUNED) return -EINVAL;
+    { DeviceGuard guard(ctx->device); resident_stop(ctx); }   // it runs the kernels chosen so far
     if (mode != ctx->search_mode) {  // captured graphs hold the old kernel
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
@@ -501,37 +577,11 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
                                   "device is %d", ctx->device, cur_dev);
 
     hipStream_t s = static_cast<hipStream_t>(stream);
-    BatchView v;
-    uint8_t *ws = static_cast<uint8_t *>(d_workspace);
-    const bool two = p.pyramid_levels == 2, eq = p.mean_subtract != 0;
-    v.prev = d_prev; v.cur = d_cur; v.stride = pair_stride;
-    v.sums = eq ? reinterpret_cast<uint32_t *>(ws + L.sums) : nullptr;
-    v.l1_prev = two ? ws + L.l1_prev : nullptr;
-    v.l1_cur = two ? ws + L.l1_cur : nullptr;
-    v.blocks1 = reinterpret_cast<aof_block *>(ws + L.l1_blocks);
-    v.subdirs1 = p.subpixel ? ws + L.l1_subdirs : nullptr;
-    v.flows1 = reinterpret_cast<aof_flow *>(ws + L.l1_flows);
-    v.hist1 = ws + L.l1_hist;
-    v.blocks0 = d_blocks ? d_blocks : reinterpret_cast<aof_block *>(ws + L.l0_blocks);
-    v.subdirs0 = nullptr;
-    if (p.subpixel) v.subdirs0 = d_subdirs ? d_subdirs : ws + L.l0_subdirs;
-    v.flows = d_flows;
-    v.hist0 = ws + L.l0_hist;
+    const BatchView v = batch_view(ctx, L, d_prev, d_cur, pair_stride, d_blocks, d_subdirs, d_flows, d_workspace);
 
-    // Small pairs (sparse grids, frames that fit LDS -- the reference's call shape): sums, pyramid,
-    // searches and reductions of a pair in one launch, one workgroup per pair.  Large batches of
-    // such pairs keep the separate kernels, whose grouped searches pack several pairs into a workgroup.
-    if (!ctx->force_generic && !ctx->split_coarse && n_pairs <= kSmallMaxPairs) {
+    {
         SmallArgs sm;
-        sm.levels = two ? 2 : 1;
-        sm.l0 = search_args(ctx, 0, v.prev, v.cur, v.stride, v.blocks0, v.subdirs0, nullptr, v.sums, n_pairs);
-        sm.l1 = search_args(ctx, 1, v.l1_prev, v.l1_cur, (int64_t)(p.width / 2) * (p.height / 2), v.blocks1, v.subdirs1,
-                            nullptr, v.sums, n_pairs);
-        sm.t0 = flow_tail(ctx, 0, v.flows, two ? v.flows1 : nullptr);
-        sm.t1 = flow_tail(ctx, 1, v.flows1, nullptr);
-        sm.sums = v.sums;
-        if (search_kind(ctx, sm.l0) == SK_LANE8_GROUP && (!two || search_kind(ctx, sm.l1) == SK_LANE8_GROUP) &&
-            flow_small_supported(sm)) {
+        if (small_args(ctx, v, n_pairs, &sm)) {
             Timed t(ctx, AOF_K_SEARCH, s);
             rc = launch_flow_small(sm, s);
             if (rc) return fail(ctx, -EIO, "small-pair launch: %s", hipGetErrorString((hipError_t)rc));
@@ -547,6 +597,7 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
 int aof_set_split_coarse(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
+    { DeviceGuard guard(ctx->device); resident_stop(ctx); }   // it runs the kernels chosen so far
     if ((on != 0) != ctx->split_coarse)   // captured graphs hold the old kernels
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
@@ -591,6 +642,7 @@ int aof_derotate_batch_device(const aof_derotate_params *p, const aof_flow *d_fl
 
 static void free_host_state(aof_ctx *ctx)
 {
+    resident_stop(ctx);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); ctx->stream = nullptr; }
     if (ctx->h_frame) { (void)hipHostFree(ctx->h_frame); ctx->h_frame = nullptr; }
     for (int i = 0; i < 2; i++) if (ctx->h_frames[i]) { (void)hipHostFree(ctx->h_frames[i]); ctx->h_frames[i] = nullptr; }
@@ -717,6 +769,7 @@ int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, ao
 }
 
 static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow, int slot);
+static int stream_push_resident(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow, int slot, bool *served);
 
 int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
 {
@@ -727,11 +780,17 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
     if (rc) return rc;
     const size_t bytes = (size_t)ctx->params.width * ctx->params.height;
     const int slot = ctx->have_prev ? 1 - ctx->cur_slot : 0;
+    if (ctx->have_prev && ctx->resident_on && ctx->zero_copy && !ctx->profiling) {
+        bool served = false;
+        rc = stream_push_resident(ctx, frame, flow, slot, &served);
+        if (served || rc) return rc;   // (not served and no error: this configuration takes the paths below)
+    }
     if (ctx->have_prev && !ctx->graph_disabled && !ctx->profiling) {
         if (!ctx->push_graph[slot]) build_push_graph(ctx, slot);
         if (ctx->push_graph[slot]) return stream_push_graph(ctx, frame, flow, slot);
     }
     uint8_t *const *frames = ctx->zero_copy ? ctx->h_frames : ctx->d_frames;
+    ctx->rframe_req[slot] = 0;   // (written outside a resident request)
     if (ctx->zero_copy) std::memcpy(ctx->h_frames[slot], frame, bytes);
     else HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[slot], frame, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->have_prev) {
@@ -753,6 +812,7 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
 // Same contract as the plain path above, one hipGraphLaunch per frame.
 static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow, int slot)
 {
+    ctx->rframe_req[slot] = 0;   // (written outside a resident request)
     std::memcpy(ctx->zero_copy ? ctx->h_frames[slot] : ctx->h_frame, frame,
                 (size_t)ctx->params.width * ctx->params.height);
     hipError_t e = hipGraphLaunch(ctx->push_graph[slot], ctx->stream);
@@ -763,6 +823,78 @@ static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow,
     }
     *flow = *ctx->h_flow;
     ctx->cur_slot = slot;
+    return 0;
+}
+
+// The resident path: post the request, make sure the kernel is there, wait for its completion word.
+// *served = false (and 0) when the one-workgroup kernel does not serve this configuration.
+static int stream_push_resident(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow, int slot, bool *served)
+{
+    const aof_params &p = ctx->params;
+    const size_t bytes = (size_t)p.width * p.height;
+    *served = false;
+    if (!ctx->box) {
+        if (hipHostMalloc((void **)&ctx->box, sizeof(ResidentBox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipStreamCreateWithFlags(&ctx->rstream, hipStreamNonBlocking) != hipSuccess) {
+            if (ctx->box) { (void)hipHostFree(ctx->box); ctx->box = nullptr; }
+            ctx->resident_on = false;
+            (void)hipGetLastError();
+            return 0;
+        }
+        std::memset(ctx->box, 0, sizeof(ResidentBox));
+    }
+    aof_ws_layout L;
+    aof_workspace_layout(&p, 1, &L);
+    // (the frame pointers of the view are placeholders: the kernel picks the two pinned frames by slot)
+    const BatchView v = batch_view(ctx, L, ctx->h_frames[0], ctx->h_frames[1], (int64_t)bytes, ctx->d_blocks, ctx->d_subdirs,
+                                   ctx->h_flow, ctx->d_ws);
+    SmallArgs sm;
+    if (!small_args(ctx, v, 1, &sm)) return 0;
+    ResidentBox *box = ctx->box;
+    std::memcpy(ctx->h_frames[slot], frame, bytes);
+    uint32_t seq = ++ctx->rseq;
+    if (seq == 0) seq = ++ctx->rseq;   // 0 means "no request" to the kernel
+    __atomic_store_n(&box->word, resident_word(seq, slot, ctx->rframe_req[1 - slot]), __ATOMIC_RELEASE);   // the frame bytes first
+    ctx->rframe_req[slot] = seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        if (__atomic_load_n(&box->done, __ATOMIC_ACQUIRE) == seq) break;
+        if (!__atomic_load_n(&box->running, __ATOMIC_ACQUIRE)) {
+            // not there (first call, or it left on its idle / lifetime deadline): start it behind its
+            // predecessor, serving from the last request that one completed
+            if (__atomic_load_n(&box->done, __ATOMIC_ACQUIRE) == seq) break;
+            __atomic_store_n(&box->running, 1u, __ATOMIC_RELEASE);
+            const int lrc = launch_flow_resident(sm, box, ctx->h_frames[0], ctx->h_frames[1],
+                                                 __atomic_load_n(&box->done, __ATOMIC_ACQUIRE), kResidentIdleTicks,
+                                                 kResidentLifeTicks, ctx->rstream);
+            if (lrc) {
+                __atomic_store_n(&box->running, 0u, __ATOMIC_RELEASE);
+                ctx->resident_on = false;
+                ctx->have_prev = false;
+                return fail(ctx, -EIO, "resident kernel launch: %s", hipGetErrorString((hipError_t)lrc));
+            }
+        }
+        if ((++spins & 0x3FFu) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kResidentHostTimeoutS) {
+            // no answer: stop it, leave the resident mode and let the caller's frame take the graph path
+            resident_stop(ctx);
+            ctx->resident_on = false;
+            return 0;
+        }
+    }
+    *flow = *ctx->h_flow;
+    ctx->cur_slot = slot;
+    *served = true;
+    return 0;
+}
+
+int aof_set_stream_resident(aof_ctx *ctx, int on)
+{
+    if (!ctx) return -EINVAL;
+    if (on < 0) return (ctx->box && __atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE)) ? 1 : 0;
+    if (!on) { DeviceGuard guard(ctx->device); resident_stop(ctx); }
+    ctx->resident_on = on != 0;
     return 0;
 }
 

@@ -163,6 +163,28 @@ int launch_search_tile16(const SearchArgs &a, void *stream);
 // Small pairs (frames fit LDS, grids <= 256 blocks), one or two levels, in one launch: one workgroup per pair.
 bool flow_small_supported(const SmallArgs &a);
 int launch_flow_small(const SmallArgs &a, void *stream);
+// The resident form of the same kernel for the per-call path: one workgroup that stays on the device and
+// serves requests posted through a mailbox in pinned host memory (k_flow_small.hip).
+struct ResidentBox {
+    // host -> device, ONE 64-bit word (one PCIe read per poll): bits 0..31 the number of the newest request
+    // (never 0), bit 32 which of the two pinned frames is the newest (the other is its predecessor), bits
+    // 33..62 the low 30 bits of the request at which that OTHER frame was posted + 1 (0 = not through a
+    // request), bit 63 = leave now
+    unsigned long long word;
+    uint32_t pad0[14];
+    uint32_t done;      // device: number of the last request served (its record is in place)
+    uint32_t running;   // host sets 1 before the launch, the device 0 when it leaves
+    uint32_t exited;    // device: `done` at the moment it left
+    uint32_t pad1[13];
+};
+constexpr unsigned long long kResidentStopBit = 1ull << 63;
+inline unsigned long long resident_word(uint32_t request, int slot, uint32_t prev_request)
+{
+    const unsigned long long prev = prev_request ? (unsigned long long)(prev_request & 0x3FFFFFFFu) + 1ull : 0ull;
+    return (unsigned long long)request | ((unsigned long long)(slot & 1) << 32) | (prev << 33);
+}
+int launch_flow_resident(const SmallArgs &a, ResidentBox *box, const uint8_t *frame_a, const uint8_t *frame_b,
+                         uint32_t served, uint64_t idle_ticks, uint64_t life_ticks, void *stream);
 int launch_reduce(const ReduceArgs &a, void *stream);
 int launch_derotate(const aof_derotate_params &p, const aof_flow *flows, const aof_gyro *gyro,
                     int64_t n, float *out, void *stream);

@@ -50,6 +50,12 @@ public:
 	bool setSearchPyramid(int levels, bool mean_subtract);
 	int getPyramidLevels() const;
 
+	// Opt-in: serve calcFlow() from a kernel that STAYS on the device and takes each frame through a
+	// mailbox in pinned memory, instead of one kernel launch per call (aof_set_stream_resident in aof.h:
+	// about 10 us per call instead of 25-35 us; the kernel leaves by itself after 50 ms without a
+	// frame and is started again by the next call).  Same results bit for bit.
+	bool setResidentKernel(bool on);
+
 	// Text of the last engine error ("ok" when healthy); never throws.
 	const char *lastError() const;
 	// False when the GPU engine could not be created (no gfx950 device).  There is no CPU
@@ -90,5 +96,6 @@ private:
 	OpticalFlow(const OpticalFlow &);
 	OpticalFlow &operator=(const OpticalFlow &);
 	aof_ctx *_ctx;
+	bool _resident;  // setResidentKernel(): carried over when the engine is re-created
 	char _err[160];
 };

@@ -58,6 +58,7 @@ int aof_facade_set_search_pyramid(void *flow, int levels, int mean_subtract)
 	return static_cast<OpticalFlow *>(flow)->setSearchPyramid(levels, mean_subtract != 0) ? 1 : 0;
 }
 int aof_facade_pyramid_levels(void *flow) { return static_cast<OpticalFlow *>(flow)->getPyramidLevels(); }
+int aof_facade_set_resident(void *flow, int on) { return static_cast<OpticalFlow *>(flow)->setResidentKernel(on != 0) ? 1 : 0; }
 
 int aof_facade_image_width(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageWidth(); }
 int aof_facade_image_height(void *flow) { return static_cast<OpticalFlow *>(flow)->getImageHeight(); }

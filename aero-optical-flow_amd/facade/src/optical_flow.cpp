@@ -14,7 +14,7 @@
 OpticalFlow::OpticalFlow(float f_length_x, float f_length_y, int ouput_rate, int img_width,
 			 int img_height)
 	: image_width(img_width), image_height(img_height), focal_length_x(f_length_x),
-	  focal_length_y(f_length_y), output_rate(ouput_rate), time_last_pub(0), _ctx(NULL)
+	  focal_length_y(f_length_y), output_rate(ouput_rate), time_last_pub(0), _ctx(NULL), _resident(false)
 {
 	std::snprintf(_err, sizeof(_err), "engine not opened");
 	initLimitRate();
@@ -57,7 +57,16 @@ bool OpticalFlow::setSearchPyramid(int levels, bool mean_subtract)
 	if (aof_create(&p, 0, &fresh)) return false;
 	aof_destroy(_ctx);
 	_ctx = fresh;
+	if (_resident) aof_set_stream_resident(_ctx, 1);
 	initLimitRate();
+	return true;
+}
+
+bool OpticalFlow::setResidentKernel(bool on)
+{
+	if (!_ctx) return false;
+	if (aof_set_stream_resident(_ctx, on ? 1 : 0)) return false;
+	_resident = on;
 	return true;
 }
 

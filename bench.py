@@ -177,6 +177,18 @@ def bench_c1(args, aof, rank, world, dist):
     for k in range(n2):
         flow2.calcFlow(frames2[k & 63], ((200 + k) * 13333) & 0xFFFFFFFF)
     out["config"]["opencv_facade_128x128_two_levels_us_per_call"] = round((time.perf_counter() - t0) / n2 * 1e6, 2)
+    # the same two call shapes served by the resident kernel (setResidentKernel: no launch per call)
+    for key, mk, fr, wh in (("resident_kernel_us_per_call", aof.OpticalFlowPX4, frames, (64, 64)),
+                            ("opencv_facade_128x128_two_levels_resident_kernel_us_per_call", aof.OpticalFlowOpenCV, frames2, (128, 128))):
+        f3 = mk(216.6677, 216.2457, 15, *wh)
+        f3.setResidentKernel(True)
+        for k in range(200):
+            f3.calcFlow(fr[k & 63], (k * 13333) & 0xFFFFFFFF)
+        t0 = time.perf_counter()
+        for k in range(n2):
+            f3.calcFlow(fr[k & 63], ((200 + k) * 13333) & 0xFFFFFFFF)
+        out["config"][key] = round((time.perf_counter() - t0) / n2 * 1e6, 2)
+        f3.close()
     if rank == 0:
         from oracle import pyoracle as orc
         o = orc.Px4(orc.px4flow_params(64, 64), 216.6677, 216.2457, 15)

@@ -180,6 +180,17 @@ int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, ao
  * the first frame after create/reset (nothing to compare, *flow zeroed), 0 afterwards. */
 int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow);
 int aof_stream_reset(aof_ctx *ctx);
+/* Opt-in resident form of the streaming entry point for small frames (the one-workgroup kernel's class:
+ * 8x8 tiles, grids of 8..256 blocks, frames of at most 64 KB).  20 of the 25 us a call takes through a
+ * replayed hipGraph are the runtime's launch and completion; with on = 1 ONE workgroup stays on the device
+ * between calls, polls a request word in pinned host memory, computes the pair exactly as the one-launch
+ * kernel does and posts the 16-byte record and a completion word the host polls -- no launch per frame.
+ * The kernel always ends by itself: after 50 ms without a request, after 200 ms in total (so nothing that
+ * waits for the device to drain, e.g. a hipFree elsewhere in the process, waits longer), or when the
+ * library stops it (aof_destroy, aof_set_*, this call with on = 0); the next call starts it again.  A
+ * request that is not answered within 250 ms stops it for good and the call falls back to the graph path.
+ * Results are bit-identical in both forms.  on < 0 queries whether the kernel is on the device now. */
+int aof_set_stream_resident(aof_ctx *ctx, int on);
 /* The streaming entry point replays a captured hipGraph (H2D frame, kernels, D2H result)
  * per call; this switches the capture off (1 = on, the default).  Returns whether a graph
  * is currently instantiated for the next call when on < 0 (query). */

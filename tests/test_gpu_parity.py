@@ -911,14 +911,17 @@ def same_outputs(got, exp, k):
         assert np.float32(got[3]).tobytes() == np.float32(exp[3]).tobytes(), (k, got, exp)
 
 
+@pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("cls", ["OpticalFlowPX4", "OpticalFlowOpenCV"])
-def test_facade_calcflow_matches_oracle(aof, orc, synth, gpu_device, cls):
+def test_facade_calcflow_matches_oracle(aof, orc, synth, gpu_device, cls, resident):
     """The C++ facade classes (calcFlow contract of mainloop.cpp:322-331) through
-    the HIP engine, against the oracle of the same semantics -- bit-exact floats."""
+    the HIP engine, against the oracle of the same semantics -- bit-exact floats; one launch per
+    call (replayed hipGraph) and served by the resident kernel (setResidentKernel)."""
     fx, fy = 216.6677, 216.2457  # /root/reference/src/main.cpp:60-61
     for rate, size in ((15, (64, 64)), (0, (64, 64)), (40, (128, 128)), (15, (128, 96)), (15, (75, 64))):
         flow = getattr(aof, cls)(fx, fy, rate, size[0], size[1])
         assert flow.lastError() == "ok"
+        assert flow.setResidentKernel(resident)
         assert (flow.getImageWidth(), flow.getImageHeight()) == size
         po, levels = facade_oracle_params(aof, orc, cls, *size)
         assert flow.getPyramidLevels() == levels
@@ -1128,6 +1131,66 @@ def test_streaming_graph_and_eager_paths_agree(aof, orc, synth, gpu_device, kw):
     assert outs[0] == outs[1]
     for k in range(1, 9):
         assert outs[0][k - 1] == orc.flow_pair(po, frames[k - 1], frames[k])["flow"].tobytes()
+
+
+@pytest.mark.parametrize("kw", [dict(px4=1), dict(px4=1, pyramid_levels=2, mean_subtract=1),
+                                dict(px4=1, size=(128, 128), pyramid_levels=2, mean_subtract=1),
+                                dict(size=(128, 96), mean_subtract=1), dict(px4=1, size=(96, 80), subpixel=0, hist_filter=0)])
+def test_resident_kernel_serves_the_streaming_entry_point(aof, orc, synth, gpu_device, kw):
+    """aof_set_stream_resident: ONE workgroup stays on the device and takes the frames through a mailbox
+    in pinned memory.  Every record must equal the oracle's (and hence the launch-per-call paths'):
+    consecutive frames (the older frame stays in LDS, only the new one crosses PCIe), a stream reset,
+    a frame that takes the graph path in between (the LDS copy must not be trusted afterwards), a
+    kernel switch (the resident kernel must step aside), a pause longer than its idle deadline (it
+    leaves by itself and the next call starts it again), and destruction while it is on the device."""
+    import time
+    kw = dict(kw)
+    W, H = kw.pop("size", (64, 64))
+    p = aof.px4flow_params(W, H, **kw) if kw.pop("px4", 0) else aof.default_params(W, H, **kw)
+    frames, _ = synth.make_sequence(W, H, 40, 4, seed=51, max_step=3)
+    po = orc.params_from(p)
+    eng = aof.FlowEngine(p, 0)
+    eng.set_stream_resident(True)
+    prev = None
+
+    def push(k, expect_resident=None):
+        nonlocal prev
+        got = eng.stream_push(frames[k])
+        if prev is None:
+            assert got is None
+        else:
+            assert got.tobytes() == orc.flow_pair(po, frames[prev], frames[k])["flow"].tobytes(), (k, prev)
+        prev = k
+        if expect_resident is not None:
+            assert eng.stream_resident_running() == expect_resident, k
+
+    push(0)
+    for k in range(1, 8):
+        push(k, True)
+    push(5, True)                      # any frame may follow any frame
+    eng.stream_reset()
+    prev = None
+    push(9)                            # first frame again: no request
+    push(10, True)                     # its predecessor was not posted through a request: both frames are fetched
+    push(11, True)
+    eng.set_stream_resident(False)     # one frame through the launch-per-call path ...
+    assert not eng.stream_resident_running()
+    push(12, False)
+    eng.set_stream_resident(True)      # ... whose pinned frame the resident kernel never saw
+    push(13, True)
+    push(14, True)
+    eng.force_generic(True)            # the one-workgroup kernel does not serve this selection
+    assert not eng.stream_resident_running()
+    push(15, False)
+    eng.force_generic(False)
+    push(16, True)
+    time.sleep(0.12)                   # beyond the 50 ms idle deadline
+    assert not eng.stream_resident_running(), "the kernel must leave by itself when no frame comes"
+    push(17, True)
+    for k in range(18, 40):            # 22 more calls; the 200 ms lifetime does not matter to results
+        push(k)
+    assert eng.stream_resident_running()
+    eng.close()                        # stops the kernel first
 
 
 def test_streaming_path_follows_kernel_switches_mid_sequence(aof, orc, synth, gpu_device):

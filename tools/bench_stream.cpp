@@ -27,20 +27,22 @@ int main(int argc, char **argv)
                 f[k][(size_t)y * w + x] = (uint8_t)(acc / 9);
             }
     }
-    for (int mode = 0; mode < 4; mode++) {
+    for (int mode = 0; mode < 5; mode++) {   // 4: the resident kernel (aof_set_stream_resident)
         if (only >= 0 && mode != only) continue;
-        const int graph = !(mode & 1), generic = mode >> 1;
+        const int graph = !(mode & 1), generic = (mode >> 1) & 1, resident = mode == 4;
         aof_ctx *ctx;
         if (aof_create(&p, 0, &ctx)) { printf("no device\n"); return 1; }
         aof_set_force_generic(ctx, generic);
         aof_set_stream_graph(ctx, graph);
+        aof_set_stream_resident(ctx, resident);
         aof_flow out;
         for (int i = 0; i < 50; i++) aof_stream_push_host(ctx, f[i & 1].data(), &out);
         auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < calls; i++) aof_stream_push_host(ctx, f[i & 1].data(), &out);
         double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
-        printf("%dx%d levels=%d %s graph=%d instantiated=%d: %.2f us per call (quality %d)\n", w, h, levels,
-               aof_search_variant(ctx), graph, aof_set_stream_graph(ctx, -1), us, out.quality);
+        printf("%dx%d levels=%d %s graph=%d instantiated=%d resident=%d on_device=%d: %.2f us per call (quality %d flow %.3f %.3f)\n",
+               w, h, levels, aof_search_variant(ctx), graph, aof_set_stream_graph(ctx, -1), resident,
+               aof_set_stream_resident(ctx, -1), us, out.quality, out.flow_x, out.flow_y);
         aof_destroy(ctx);
     }
     return 0;
