@@ -2,7 +2,7 @@
 // pixel sums + 2x2 box pyramid (K1), the level-1 8x8 SAD search over +-4 (K2 at level 1) and
 // its histogram-filtered reduction to the level-0 predictor (K3 at level 1).
 //
-// One workgroup of 1024 threads owns one frame pair and keeps BOTH level-1 frames in LDS
+// One workgroup of 512 threads owns one frame pair and keeps BOTH level-1 frames in LDS
 // (2 * W/2 * H/2 bytes: 150 KB at VGA -- the reason CDNA4's 160 KB LDS per CU matters here), so
 // the level-1 frames are never written to HBM and never read back:
 //   phase 1  streams the pair's two frames once (16 B per lane from two adjacent rows, many loads
@@ -10,7 +10,7 @@
 //   phase 2  equalises the level-1 `cur` frame in place (each pixel once, not once per window);
 //   phase 3  gates every block (4x4 gradient) and searches: one lane per (block, dy row) item,
 //            dy-major, so a wave reads 64 neighbouring windows of one row -- conflict-free
-//            ds_read_b64 -- and 9 * nb items fill 1024 lanes to 99 %; the nine dy rows of a block
+//            ds_read_b64 -- and 9 * nb items fill 512 lanes to 99 %; the nine dy rows of a block
 //            meet in an LDS atomicMin on the packed key (sad << 16 | idx) = first minimum wins;
 //   phase 4  writes the level-1 records, votes, and wave 0 finalises the predictor -- while the other
 //            waves already stream the workgroup's next pair (two sets of histograms take turns).
@@ -30,7 +30,10 @@ namespace aof {
 
 namespace {
 
-constexpr int kThreads = 1024;
+// 512 lanes = two waves per SIMD (127 VGPRs): alone the kernel is as fast as with 1 024 lanes (171 us against
+// 174 us per 1 024 VGA pairs), and it leaves half of the CU's registers and wave slots to the level-0
+// search waves of ANOTHER batch in flight (bench.py --streams 2: 407 -> 398 us per C3 step, round 3)
+constexpr int kThreads = 512;
 constexpr int kUnroll = 4;            // sweeps per batch; two batches = 16 loads of 16 B in flight per lane
 constexpr uint32_t kGated = 0xFFFFFFFEu;   // key of a block the gradient gate rejected
 constexpr uint32_t kOpen = 0xFFFFFFFFu;    // key of a block still waiting for its first candidate
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
     const int rpi = a.rows_per_sweep;                        // level-1 rows per sweep of the workgroup (launcher)
     int yoff = (int)fast_div((uint32_t)tid, a.div_chunks), col = tid - yoff * chunks;
     const bool active = yoff < rpi;
-    if (!active) { yoff = 0; col = 0; }   // idle lanes (24 of 1024 at VGA) load valid bytes and drop them
+    if (!active) { yoff = 0; col = 0; }   // idle lanes (32 of 512 at VGA: 12 rows of 40 chunks) load valid bytes and drop them
     // sweeps never straddle the two frames: nkf sweeps per frame, prev first (k < nkf), then cur
     const int nkf = (h1 + rpi - 1) / rpi, nk = 2 * nkf;
     const int nk_pad = (nk + 2 * kUnroll - 1) / (2 * kUnroll) * (2 * kUnroll);   // whole rounds of two batches
