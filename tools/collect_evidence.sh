@@ -3,12 +3,16 @@
 # HBM-traffic PMC passes for the bench workloads, all under gpurun_out/evidence/.
 # rocprofv3 gets the program itself after "--" and --pmc is never combined with other traces
 # than --kernel-trace.   usage: tools/collect_evidence.sh [workload ...]   (default: all)
+# Besides the workloads of bench.py --workload, "share" collects configs[3]'s per-GPU share: the
+# 128-pair C2 step with one batch in flight / separate K3 and with two batches in flight / the
+# reduction inside the search launch, next to the 1 024-pair step of the same box; "lanes" the
+# multi-kernel workloads with two batches in flight; "latency" the per-call path.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/evidence
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-WL=${@:-c2 c3 c5 c2h c1b c5h ingest derotate}
+WL=${@:-c2 c3 c5 c2h c1b c5h ingest derotate share lanes latency}
 args_of() {   # bench.py arguments and the launch size key of a workload
     case $1 in
         c5|c5h) echo "--pairs 256";;
@@ -19,15 +23,47 @@ args_of() {   # bench.py arguments and the launch size key of a workload
     esac
 }
 key_of() { case $1 in c5|c5h) echo 256;; c1b) echo 65536;; ingest) echo 8192;; derotate) echo 1048576;; *) echo 1024;; esac; }
+trace() {   # tag, bench arguments...: kernel-trace summary of one bench command
+    tag=$1; shift
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -- python3 $R/bench.py "$@" --cpu-seconds 0 > $O/kt_$tag.log 2>&1 || { echo "kernel trace $tag failed"; tail -3 $O/kt_$tag.log; exit 1; }
+    python3 $R/tools/summarize_rocprof.py $(ls $O/kt_$tag/*/*kernel_stats.csv | head -1) "bench.py $* --cpu-seconds 0" | grep -v "at::native\|Memset\|elementwise\|Cijk\|rocprim\|vectorized" > $O/kernel_stats_$tag.txt
+    rm -rf $O/kt_$tag
+}
+line() {   # tag, bench arguments...
+    tag=$1; shift
+    timeout -k 10 300 python3 $R/bench.py "$@" > $O/bench_$tag.json 2> $O/bench_$tag.err || { echo "bench $tag failed"; tail -3 $O/bench_$tag.err; exit 1; }
+}
 for wl in $WL; do
-    extra=$(args_of $wl)
-    timeout -k 10 300 python3 $R/bench.py --workload $wl $extra > $O/bench_$wl.json 2> $O/bench_$wl.err || { echo "bench $wl failed"; tail -3 $O/bench_$wl.err; exit 1; }
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$wl -- python3 $R/bench.py --workload $wl $extra --cpu-seconds 0 > $O/kt_$wl.log 2>&1 || { echo "kernel trace $wl failed"; exit 1; }
-    python3 $R/tools/summarize_rocprof.py $(ls $O/kt_$wl/*/*kernel_stats.csv | head -1) "bench.py --workload $wl $extra --cpu-seconds 0" | grep -v "at::native\|Memset\|elementwise\|Cijk\|rocprim\|vectorized" > $O/kernel_stats_$wl.txt
-    rm -rf $O/kt_$wl
-    echo "$wl done"
+    case $wl in
+    share)
+        line share_p1024 --cpu-seconds 0
+        line share_p128_one_batch_separate --pairs 128 --steps 200 --streams 1 --reduce separate --cpu-seconds 0
+        line share_p128_one_batch_fused --pairs 128 --steps 200 --streams 1 --reduce fused --cpu-seconds 0
+        line share_p128_two_batches_separate --pairs 128 --steps 200 --streams 2 --reduce separate --cpu-seconds 0
+        line share_p128 --pairs 128 --steps 200 --cpu-seconds 0
+        line share_p128_eager --pairs 128 --steps 200 --graph off --cpu-seconds 0
+        trace share_p128_one_batch_separate --pairs 128 --steps 200 --streams 1 --reduce separate
+        trace share_p128 --pairs 128 --steps 200
+        echo "share done";;
+    lanes)
+        for w2 in c2 c3 c2h c1b; do
+            line lanes_$w2 --workload $w2 $(args_of $w2) --streams 2 --cpu-seconds 0
+        done
+        line lanes_c3_p512 --workload c3 --pairs 512 --streams 2 --cpu-seconds 0
+        echo "lanes done";;
+    latency)
+        cd $R && tools/stream_latency.sh > $O/stream_latency.txt 2>&1; cd /tmp
+        timeout -k 10 200 python3 $R/bench.py --workload c1 --pairs 256 --steps 20 > $O/bench_c1.json 2> $O/bench_c1.err || { echo "bench c1 failed"; exit 1; }
+        echo "latency done";;
+    *)
+        extra=$(args_of $wl)
+        line $wl --workload $wl $extra
+        trace $wl --workload $wl $extra
+        echo "$wl done";;
+    esac
 done
 for wl in $WL; do
+    case $wl in share|lanes|latency) continue;; esac
     extra=$(args_of $wl); pairs=$(key_of $wl)
     for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"; do
         tag=$(echo $set | cut -d" " -f1)
