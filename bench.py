@@ -376,7 +376,7 @@ def main():
                          "place where it measured faster (one kernel per batch leaves no gap for the other lane)")
     ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="replay one step's launch sequence as a hipGraph: auto (default) = for N > 1 and for "
-                         "launch-bound steps (fewer than 2 Mi blocks per step), on, off")
+                         "launch-bound steps (fewer than 8 G abs-diffs per step), on, off")
     ap.add_argument("--streams", type=int, default=0,
                     help="independent batches in flight: step i runs on HIP stream i %% S with its own context, "
                          "record buffers and workspace.  0 (default) = automatic: 2 when a step is launch-bound "
@@ -441,8 +441,9 @@ def main():
             sys.exit("--scaling strong needs --pairs divisible by the number of GPUs")
     else:
         n = args.pairs
+    launch_bound = aof.abs_diffs(p) * n < 8e9   # a few dozen microseconds of search per step (C2: up to 330 pairs)
     if args.streams <= 0:
-        args.streams = 2 if n * eng.nblocks(0) < (1 << 21) else 1
+        args.streams = 2 if launch_bound else 1
     reduce_mode = args.reduce
     if reduce_mode == "auto":
         reduce_mode = "fused" if args.streams > 1 and n <= 512 else "separate"
@@ -487,7 +488,7 @@ def main():
     ws = lanes[0].ws
     state = {"i": 0, "pending": None, "gathered": None, "last": (lanes[0], 0)}
     multi = len(lanes) > 1
-    use_graph = args.graph == "on" or (args.graph == "auto" and (world > 1 or n * nb < (1 << 21)))
+    use_graph = args.graph == "on" or (args.graph == "auto" and (world > 1 or launch_bound))
     if use_graph:   # a short step is launch-bound: replay it as one hipGraph
         for ln in lanes:
             ln.graphs = []
@@ -563,7 +564,7 @@ def main():
     lanes[0].enqueue[0]()
     fence()
     lps = max(1, len(eng.profile_ms(aof.K_SEARCH)))   # K2 launches per step (a batch of more than 2^31 blocks is cut into several)
-    events_in_timed_region = lps == 1 and not use_graph and not multi and n * nb >= (1 << 21)
+    events_in_timed_region = lps == 1 and not use_graph and not multi and not launch_bound
     eng.set_profiling(events_in_timed_region, kernels=[aof.K_SEARCH])
     for _ in range(args.warmup):
         step()

@@ -37,6 +37,7 @@ for wl in $WL; do
     case $wl in
     share)
         line share_p1024 --cpu-seconds 0
+        line share_p1024_two_batches --streams 2 --cpu-seconds 0
         line share_p128_one_batch_separate --pairs 128 --steps 200 --streams 1 --reduce separate --cpu-seconds 0
         line share_p128_one_batch_fused --pairs 128 --steps 200 --streams 1 --reduce fused --cpu-seconds 0
         line share_p128_two_batches_separate --pairs 128 --steps 200 --streams 2 --reduce separate --cpu-seconds 0

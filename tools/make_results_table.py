@@ -1,36 +1,121 @@
 #!/usr/bin/env python3
-"""Markdown table of the committed bench lines profiles/<prefix>_bench_*.json (README / DESIGN)."""
-import glob
+"""Markdown tables of the committed bench lines profiles/<prefix>_bench_*.json, written between the
+<!-- results:begin/end --> and <!-- share:begin/end --> markers of DESIGN.md (idempotent).
+    python tools/make_results_table.py [profiles/r03_final]"""
 import json
 import os
+import re
 import sys
 
-prefix = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02_final"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prefix = sys.argv[1] if len(sys.argv) > 1 else "profiles/r03_final"
 order = ["c2", "c3", "c2h", "c5", "c5h", "c1b", "ingest", "derotate"]
 names = {"c2": "`c2` 640×480, 8×8 SAD, ±4, dense grid — the headline", "c3": "`c3` = c2 + 2-level pyramid + mean equalisation",
          "c2h": "`c2h` = c2 + half-pixel refinement", "c5": "`c5` 1280×960, 16×16 SAD, ±8 (256 pairs per launch)",
          "c5h": "`c5h` = c5 + half-pixel refinement", "c1b": "`c1b` 64×64, published sparse grid + half-pixel, 65 536 pairs per launch",
          "ingest": "`ingest` 640×480 sensor frames → 128×128 crop + exposure histogram", "derotate": "`derotate` gyro de-rotation of flow records"}
-print("| workload (`bench.py --workload`) | throughput | step | whole step vs 8 TB/s | dominant kernel: time, vs 8 TB/s | beyond-L2 traffic / algorithmic | exact-pruned (opt-in) | CPU oracle |")
-print("|---|---|---|---|---|---|---|---|")
-for w in order:
-    f = f"{prefix}_bench_{w}.json"
+
+
+def load(tag):
+    f = os.path.join(ROOT, f"{prefix}_bench_{tag}.json")
     if not os.path.exists(f):
-        continue
-    j = json.loads(open(f).read().strip().splitlines()[-1])
-    r = j["roofline"]
+        return None
+    return json.loads(open(f).read().strip().splitlines()[-1])
+
+
+def fmt_value(j):
     unit = j["unit"].replace("frame-pairs/s", "pairs/s")
     v = j["value"]
-    val = f"{v/1e6:.2f} M {unit}" if v < 1e9 else f"{v/1e9:.1f} G {unit}"
-    step = f"{j['ms_per_step']:.4f} ms"
-    fs = f"**{100*r['frac_step']:.1f} %**" if r.get("frac_step") else "—"
-    per = r.get("pairs_per_launch") or r.get("frames_per_launch") or r.get("records_per_launch")
-    alg = (r.get("algorithmic_bytes_per_pair") or r.get("algorithmic_bytes_per_frame") or r.get("algorithmic_bytes_per_record")) * per
-    t = r.get("traffic_step") or r.get("traffic")
-    tr = f"{t/alg:.2f}×" if t else "—"
-    dom = f"{r['kernel'].split(' ')[0]} {r['kernel_ms']*1e3:.1f} µs, {100*r['frac']:.1f} %"
-    pr = j.get("exact_pruned_search")
-    prs = f"{pr['per_gpu_value']/1e6:.2f} M ({100*pr['roofline_frac']:.1f} %)" if pr else "—"
-    cb = j.get("cpu_baseline")
-    cbs = f"{cb['value']:,.0f} /s on {cb['cores']} core{'s' if cb['cores'] > 1 else ''}" if cb else "—"
-    print(f"| {names[w]} | {val} | {step} | {fs} | {dom} | {tr} | {prs} | {cbs} |")
+    return f"{v/1e6:.2f} M {unit}" if v < 1e9 else f"{v/1e9:.1f} G {unit}"
+
+
+def results():
+    out = ["| workload (`bench.py --workload`) | throughput | step | whole step vs 8 TB/s | dominant kernel: time, vs 8 TB/s | beyond-L2 traffic / algorithmic | two batches in flight (`--streams 2`) | exact-pruned (opt-in) | CPU oracle |",
+           "|---|---|---|---|---|---|---|---|---|"]
+    for w in order:
+        j = load(w)
+        if not j:
+            continue
+        r = j["roofline"]
+        step = f"{j['ms_per_step']:.4f} ms"
+        fs = f"**{100*r['frac_step']:.1f} %**" if r.get("frac_step") else "—"
+        per = r.get("pairs_per_launch") or r.get("frames_per_launch") or r.get("records_per_launch")
+        alg = (r.get("algorithmic_bytes_per_pair") or r.get("algorithmic_bytes_per_frame") or r.get("algorithmic_bytes_per_record")) * per
+        t = r.get("traffic_step") or r.get("traffic")
+        tr = f"{t/alg:.2f}×" if t else "—"
+        dom = f"{r['kernel'].split(' ')[0]} {r['kernel_ms']*1e3:.1f} µs, {100*r['frac']:.1f} %"
+        pr = j.get("exact_pruned_search")
+        prs = f"{pr['per_gpu_value']/1e6:.2f} M ({100*pr['roofline_frac']:.1f} %)" if pr else "—"
+        cb = j.get("cpu_baseline")
+        cbs = "—"
+        if cb:
+            cbs = f"{cb['value']:,.0f} /s on {cb['cores']} core{'s' if cb['cores'] > 1 else ''}"
+            if cb.get("single_thread"):
+                cbs += f", {cb['single_thread']['value']:,.0f} /s on one"
+        l2 = load("lanes_" + w)
+        ls = "—"
+        if l2:
+            ls = f"{fmt_value(l2)}"
+            if l2["roofline"].get("frac_step"):
+                ls += f" (**{100*l2['roofline']['frac_step']:.1f} %**)"
+        out.append(f"| {names[w]} | {fmt_value(j)} | {step} | {fs} | {dom} | {tr} | {ls} | {prs} | {cbs} |")
+    c1 = load("c1")
+    if c1:
+        c = c1["config"]
+        out += ["", f"Per `calcFlow()` call through the Python harness (`bench.py --workload c1`; from C++: `profiles/{os.path.basename(prefix).split('_')[0]}_stream_latency.txt`): "
+                f"64×64 one level {c['us_per_call']} µs per call replayed as a hipGraph, **{c.get('resident_kernel_us_per_call')} µs served by the resident kernel**; "
+                f"`OpticalFlowOpenCV` at 128×128 (two levels + equalisation) {c.get('opencv_facade_128x128_two_levels_us_per_call')} µs, "
+                f"**{c.get('opencv_facade_128x128_two_levels_resident_kernel_us_per_call')} µs resident**; the CPU oracle on one core: "
+                f"{1e6/c1['cpu_baseline']['value']:.1f} µs." if c1.get("cpu_baseline") else ""]
+    return "\n".join(out)
+
+
+def share():
+    rows = [("share_p1024", "1 024 pairs, one batch in flight, separate K3 (the headline configuration)"),
+            ("share_p1024_two_batches", "1 024 pairs, two batches in flight"),
+            ("share_p128_one_batch_separate", "128 pairs, one batch in flight, separate K3 (round 2's structure + the 1 024-lane K3, graph replay)"),
+            ("share_p128_one_batch_fused", "128 pairs, one batch in flight, reduction in the search launch"),
+            ("share_p128_two_batches_separate", "128 pairs, two batches in flight, separate K3"),
+            ("share_p128", "128 pairs, `bench.py --pairs 128` as it chooses itself: two batches in flight, graph replay, reduction in the launch"),
+            ("share_p128_eager", "the same, launched eagerly (`--graph off`)")]
+    base = load("share_p1024")
+    if not base:
+        return "(not collected)"
+    best = load("share_p1024_two_batches") or base   # the fastest way one GPU runs the 1 024 pairs
+    if best["ms_per_step"] > base["ms_per_step"]:
+        best = base
+    out = ["", "", "| step | time per step | pairs/s on one GPU | headline 1 024-pair step ÷ this step | fastest 1 024-pair step ÷ this step |", "|---|---|---|---|---|"]
+    for tag, name in rows:
+        j = load(tag)
+        if not j:
+            continue
+        r1, r2 = base["ms_per_step"] / j["ms_per_step"], best["ms_per_step"] / j["ms_per_step"]
+        big = tag.startswith("share_p1024")
+        bold = tag == "share_p128"
+        out.append(f"| {name} | {j['ms_per_step']*1e3:.1f} µs | {j['value']/1e6:.2f} M | {'—' if big else (f'**{r1:.2f}×**' if bold else f'{r1:.2f}×')} | "
+                   f"{'—' if big else (f'**{r2:.2f}×**' if bold else f'{r2:.2f}×')} |")
+    j = load("share_p128")
+    if j:
+        out += ["", f"Eight GPUs that each take 128 of the 1 024 pairs therefore finish a step in {j['ms_per_step']*1e3:.1f} µs where one GPU takes "
+                    f"{best['ms_per_step']*1e3:.1f} µs for all of them at its fastest ({base['ms_per_step']*1e3:.1f} µs in the headline configuration): "
+                    f"{best['ms_per_step']/j['ms_per_step']:.1f}× before the gather (16 KB per rank, asynchronous, overlapped with the next step), "
+                    "against the ≥ 6× `north_star` asks for.  With one batch in flight the same share is launch-bound (≈ 4.7 µs of every "
+                    "replayed graph are launch gaps, 5 µs the reduction) and stays below 6×: the two batches in flight are what the target needs."]
+    return "\n".join(out)
+
+
+def put(text, tag, body):
+    b, e = f"<!-- {tag}:begin -->", f"<!-- {tag}:end -->"
+    block = f"{b}\n{body}\n{e}"
+    if b in text:
+        return re.sub(re.escape(b) + r".*?" + re.escape(e), lambda m: block, text, flags=re.S)
+    return text.replace({"results": "RESULTS_TABLE_PLACEHOLDER", "share": "SHARE_PLACEHOLDER"}[tag], block)
+
+
+path = os.path.join(ROOT, "DESIGN.md")
+text = open(path).read()
+text = put(text, "results", results())
+text = put(text, "share", share())
+open(path, "w").write(text)
+print(results())
+print(share())
