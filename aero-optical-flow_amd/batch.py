@@ -29,6 +29,12 @@ class PendingGather:
     def __init__(self, work, out, n_total, width, world):
         self.work, self.out, self.n_total, self.width, self.world = work, out, n_total, width, world
 
+    def wait_host(self):
+        """Blocks the HOST until the collective has completed (no stream is made to wait)."""
+        if self.work is not None:
+            while not self.work.is_completed():
+                pass
+
     def wait(self):
         """Blocks the CURRENT STREAM (not the host, on GPUs) until the records have landed
         and returns them as [n_total, 16] in pair order."""
@@ -44,14 +50,15 @@ class PendingGather:
         return torch.cat(parts, dim=0)
 
 
-def gather_flows_async(local_flows, n_total: int, group=None) -> PendingGather:
+def gather_flows_async(local_flows, n_total: int, group=None, force=False, out=None) -> PendingGather:
     """Starts the gather and returns at once, so the next batch's search can be enqueued
     while the 16-byte records cross xGMI (the collective runs on RCCL's own stream).
-    `local_flows` must stay untouched until wait() -- alternate two buffers."""
+    `local_flows` must stay untouched until wait() -- alternate two buffers.  `out`: optional
+    [world * ceil(n_total / world), 16] buffer to gather into."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return PendingGather(None, local_flows, n_total, n_total, 1)
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+        return PendingGather(None, local_flows, n_total, n_total, 1)   # (force: issue the collective with one rank all the same)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     b, e = shard_range(n_total, rank, world)
     assert local_flows.shape[0] == e - b and local_flows.shape[1] == 16
@@ -60,6 +67,8 @@ def gather_flows_async(local_flows, n_total: int, group=None) -> PendingGather:
     if e - b != width:
         padded = torch.zeros((width, 16), dtype=torch.uint8, device=local_flows.device)
         padded[:e - b] = local_flows
-    out = torch.empty((world * width, 16), dtype=torch.uint8, device=local_flows.device)
+    if out is None:   # (a caller that gathers every step passes its own buffer: no allocation per step)
+        out = torch.empty((world * width, 16), dtype=torch.uint8, device=local_flows.device)
+    assert out.shape == (world * width, 16) and out.dtype == torch.uint8
     work = dist.all_gather_into_tensor(out, padded.contiguous(), group=group, async_op=True)
     return PendingGather(work, out, n_total, width, world)

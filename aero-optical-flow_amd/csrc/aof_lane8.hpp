@@ -64,6 +64,9 @@ __device__ __forceinline__ uint32_t exhaustive_search(const uint4 (&win)[16], co
             acc_8[d] = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], acc_8[d]);
         }
     }
+    // Keys and minimum strictly BEHIND the SAD stream: that is the order hipcc finds by itself in the plain
+    // search kernel; in the kernel that also reduces it interleaves the two, which costs 3.5 % (round 3).
+    __builtin_amdgcn_sched_barrier(0);
     uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
     for (int d = 0; d < 9; d++) {

@@ -375,12 +375,18 @@ def main():
                          "fused when several batches are in flight and the launch has at most 512 pairs -- the only "
                          "place where it measured faster (one kernel per batch leaves no gap for the other lane)")
     ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
-                    help="replay one step's launch sequence as a hipGraph: auto (default) = for N > 1 and for "
-                         "launch-bound steps (fewer than 8 G abs-diffs per step), on, off")
+                    help="replay one step's launch sequence as a hipGraph: auto (default) = for launch-bound steps "
+                         "(fewer than 8 G abs-diffs per step), on, off")
     ap.add_argument("--streams", type=int, default=0,
                     help="independent batches in flight: step i runs on HIP stream i %% S with its own context, "
                          "record buffers and workspace.  0 (default) = automatic: 2 when a step is launch-bound "
                          "(fewer than 2 Mi blocks: configs[3]'s 128 pairs per GPU), else 1")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="N > 1: steps of a lane whose flow records one all_gather ships (0 = automatic: 4, and 16 for "
+                         "launch-bound steps)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the per-step gather even with ONE rank: rehearses the "
+                         "N > 1 code path (RCCL, graph capture beside its watchdog thread) on a one-GPU box")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="rehearse the N>1 control flow without a GPU: rendezvous, shard, gather a batch of "
                          "placeholder flow records over gloo, print one line and leave (CPU test of the launch path)")
@@ -402,8 +408,13 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -467,6 +478,9 @@ def main():
     # the next one (independent batches in flight on separate HIP streams).
     class Lane:
         pass
+    G = 1
+    if dist is not None:
+        G = args.gather_every if args.gather_every > 0 else (16 if launch_bound else 4)
     lanes = []
     for li in range(max(1, args.streams)):
         ln = Lane()
@@ -477,7 +491,16 @@ def main():
         ln.blocks = torch.empty((n, nb), dtype=torch.int32, device=device)
         ln.sub = torch.empty((n, nb), dtype=torch.uint8, device=device) if p.subpixel else None
         ln.ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=device)
-        ln.flows = [torch.empty((n, 16), dtype=torch.uint8, device=device) for _ in range(2 if args.streams <= 1 else 1)]
+        # The flow records of G consecutive steps of a lane land in one ring segment, and ONE all_gather
+        # per G steps ships it (RCCL and torch's collective call cost 25-40 us of host time and a
+        # cross-queue dependency per call: per step that was +14 us on a 1 024-pair step and made a 128-pair
+        # step host-bound; every step's records still cross xGMI inside the timed region).  Two segments per
+        # lane take turns; the compute stream never WAITS for a gather -- before a segment is written again
+        # the HOST checks that the gather that read it has completed.
+        ln.rings = [torch.empty((G, n, 16), dtype=torch.uint8, device=device) for _ in range(2)]
+        ln.flows = [ln.rings[r][g] for r in range(2) for g in range(G)]
+        ln.reads = [None, None]    # the gather in flight that reads ring segment r
+        ln.gathered = [torch.empty((world * G * n, 16), dtype=torch.uint8, device=device) for _ in range(2)] if dist is not None else None
         ln.enqueue = [ln.eng.bind_batch(prev, cur, ln.blocks, f, ln.ws, subdirs=ln.sub,
                                         stream=ln.stream.cuda_stream if args.streams > 1 else None)
                       for f in ln.flows]   # one ctypes call per step
@@ -488,7 +511,7 @@ def main():
     ws = lanes[0].ws
     state = {"i": 0, "pending": None, "gathered": None, "last": (lanes[0], 0)}
     multi = len(lanes) > 1
-    use_graph = args.graph == "on" or (args.graph == "auto" and (world > 1 or launch_bound))
+    use_graph = args.graph == "on" or (args.graph == "auto" and launch_bound)
     if use_graph:   # a short step is launch-bound: replay it as one hipGraph
         for ln in lanes:
             ln.graphs = []
@@ -510,21 +533,27 @@ def main():
         ln.i += 1
         state["i"] += 1
         state["last"] = (ln, k)
+        r, g = divmod(k, G)
+        if dist is not None and g == 0 and ln.reads[r] is not None:   # (2 G steps of this lane ago: done long since)
+            ln.reads[r].wait_host()
+            ln.reads[r] = None
         if ln.graphs is not None and not eng_profiling["on"]:
             if multi:
                 torch.cuda.set_stream(ln.stream)
             ln.graphs[k].replay()
         else:
             ln.enqueue[k]()
-        if world == 1:
+        if dist is None:
+            return
+        if g != G - 1:
             return
         if multi:
             torch.cuda.set_stream(ln.stream)
-        if state["pending"] is not None:
-            state["gathered"] = state["pending"].wait()
-        f = ln.flows[k]
-        src = f.cpu() if args.backend == "gloo" else f  # gloo (rehearsal) gathers host copies
-        state["pending"] = batch.gather_flows_async(src, world * n)
+        seg = ln.rings[r].view(G * n, 16)
+        src = seg.cpu() if args.backend == "gloo" else seg  # gloo (rehearsal) gathers host copies
+        state["pending"] = batch.gather_flows_async(src, world * G * n, force=args.force_dist,
+                                                    out=ln.gathered[r] if args.backend == "nccl" else None)
+        ln.reads[r] = state["pending"]
 
     eng_profiling = {"on": False}
     _set_prof = eng.set_profiling
@@ -535,6 +564,11 @@ def main():
     eng.set_profiling = set_profiling
 
     def drain():
+        for ln in lanes:
+            for k, g in enumerate(getattr(ln, "reads", [])):
+                if g is not None:
+                    g.wait_host()
+                    ln.reads[k] = None
         if state["pending"] is not None:
             state["gathered"] = state["pending"].wait()
             state["pending"] = None
@@ -542,7 +576,7 @@ def main():
     def fence():
         drain()
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -596,7 +630,7 @@ def main():
             lanes[0].enqueue[0]()
         fence()
     eng.set_profiling(False)
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -646,7 +680,7 @@ def main():
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_gpu": n, "global_pairs": world * n,
                    "search_kernel": eng.variant, "search": args.search, "coarse": args.coarse, "reduce": reduce_mode,
-                   "streams": len(lanes), "graph_replay": bool(use_graph), "k2_launches_per_step": lps, "noise_lsb": args.noise, "exposure_step": brightness, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend})"
+                   "streams": len(lanes), "graph_replay": bool(use_graph), "k2_launches_per_step": lps, "noise_lsb": args.noise, "exposure_step": brightness, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend}) every {G} steps per lane"
                    if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -752,7 +786,7 @@ def main():
                                              f"C oracle (-O2, SAD via {'SSE2 psadbw' if simd else 'the byte loop'}), "
                                              f"OpenMP over pairs, {spent:.1f} s"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
