@@ -681,7 +681,7 @@ def main():
         "config": {"workload": desc, "pairs_per_gpu": n, "global_pairs": world * n,
                    "search_kernel": eng.variant, "search": args.search, "coarse": args.coarse, "reduce": reduce_mode,
                    "streams": len(lanes), "graph_replay": bool(use_graph), "k2_launches_per_step": lps, "noise_lsb": args.noise, "exposure_step": brightness, "parallelism": f"pairs sharded x{world}, flows all_gather ({args.backend}) every {G} steps per lane"
-                   if world > 1 else "single GPU"},
+                   if dist is not None else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": traffic_source,

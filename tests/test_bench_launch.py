@@ -67,3 +67,17 @@ def test_four_ranks_with_two_batches_in_flight_on_one_gpu():
     assert j["n_gpus"] == 4 and c["global_pairs"] == 512 and c["pairs_per_gpu"] == 128
     assert c["streams"] == 2 and c["reduce"] == "fused" and c["graph_replay"]
     assert j["value"] > 0 and j["parity"]["oracle_pairs_bit_exact"] and j["parity"]["all_pairs_return_known_shift"]
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_rehearsal_of_the_gather_path():
+    """`bench.py --force-dist`: the N > 1 code path with ONE rank on the one-GPU box -- RCCL initialised,
+    the step captured into a hipGraph beside its watchdog thread, the flow records of G steps shipped by
+    one all_gather_into_tensor, completion checked from the host -- for the headline step and for
+    configs[3]'s per-GPU share (two lanes, reduction in the launch)."""
+    j = run_bench("--force-dist", "--steps", "40", "--warmup", "2", "--settle-steps", "20", "--cpu-seconds", "0")
+    assert j["config"]["streams"] == 1 and "every 4 steps" in j["config"]["parallelism"]
+    assert j["parity"]["oracle_pairs_bit_exact"] and j["parity"]["all_pairs_return_known_shift"]
+    k = run_bench("--force-dist", "--pairs", "128", "--steps", "64", "--warmup", "2", "--settle-steps", "20", "--cpu-seconds", "0")
+    assert k["config"]["streams"] == 2 and k["config"]["graph_replay"] and "every 16 steps" in k["config"]["parallelism"]
+    assert k["parity"]["oracle_pairs_bit_exact"] and k["parity"]["all_pairs_return_known_shift"]

@@ -45,6 +45,17 @@ def _worker(rank, world, port, n_total, out_dir):
         pending = batch.gather_flows_async(local.clone(), n_total)
         again = pending.wait()
         assert torch.equal(again, full)
+        # the form bench.py uses for N > 1: the records of G steps in one ring segment, ONE collective
+        # into a buffer of the caller, completion checked from the host (no stream waits)
+        if n_total % world == 0 and n_total > 0:
+            G, per = 3, n_total // world
+            seg = torch.stack([local + g for g in range(G)]).view(G * per, 16)   # (byte values wrap: still a unique tag per step)
+            out = torch.zeros((world * G * per, 16), dtype=torch.uint8)
+            pend = batch.gather_flows_async(seg, world * G * per, out=out)
+            pend.wait_host()
+            got = out.view(world, G, per, 16)
+            for g in range(G):
+                assert torch.equal(got[:, g].reshape(n_total, 16), full + g), g
         np.save(os.path.join(out_dir, f"rank{rank}.npy"), full.numpy())
         dist.barrier()
     finally:
