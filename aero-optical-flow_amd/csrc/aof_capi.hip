@@ -846,26 +846,32 @@ static int stream_push_resident(aof_ctx *ctx, const uint8_t *frame, aof_flow *fl
     aof_ws_layout L;
     aof_workspace_layout(&p, 1, &L);
     // (the frame pointers of the view are placeholders: the kernel picks the two pinned frames by slot)
+    // (the kernel's own copy of the record goes to device memory; the host's comes tagged, below)
     const BatchView v = batch_view(ctx, L, ctx->h_frames[0], ctx->h_frames[1], (int64_t)bytes, ctx->d_blocks, ctx->d_subdirs,
-                                   ctx->h_flow, ctx->d_ws);
+                                   ctx->d_flow, ctx->d_ws);
     SmallArgs sm;
     if (!small_args(ctx, v, 1, &sm)) return 0;
     ResidentBox *box = ctx->box;
     std::memcpy(ctx->h_frames[slot], frame, bytes);
     uint32_t seq = ++ctx->rseq;
     if (seq == 0) seq = ++ctx->rseq;   // 0 means "no request" to the kernel
+    volatile uint32_t *tagged = &reinterpret_cast<volatile uint32_t *>(ctx->h_flow)[2];
+    const uint32_t tag = seq << 24;
+    if ((*tagged & 0xFF000000u) == tag) *tagged ^= 0x80000000u;   // (first use, or a record of another path: make its tag differ)
     __atomic_store_n(&box->word, resident_word(seq, slot, ctx->rframe_req[1 - slot]), __ATOMIC_RELEASE);   // the frame bytes first
     ctx->rframe_req[slot] = seq;
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
+    // The record arrives as ONE 16-byte store whose top `count` byte carries the request's low byte: poll
+    // for that tag (the record in place is the previous request's, whose tag differs).
     for (;;) {
-        if (__atomic_load_n(&box->done, __ATOMIC_ACQUIRE) == seq) break;
+        if ((*tagged & 0xFF000000u) == tag) break;
         if (!__atomic_load_n(&box->running, __ATOMIC_ACQUIRE)) {
             // not there (first call, or it left on its idle / lifetime deadline): start it behind its
             // predecessor, serving from the last request that one completed
-            if (__atomic_load_n(&box->done, __ATOMIC_ACQUIRE) == seq) break;
+            if ((*tagged & 0xFF000000u) == tag) break;
             __atomic_store_n(&box->running, 1u, __ATOMIC_RELEASE);
-            const int lrc = launch_flow_resident(sm, box, ctx->h_frames[0], ctx->h_frames[1],
+            const int lrc = launch_flow_resident(sm, box, ctx->h_flow, ctx->h_frames[0], ctx->h_frames[1],
                                                  __atomic_load_n(&box->done, __ATOMIC_ACQUIRE), kResidentIdleTicks,
                                                  kResidentLifeTicks, ctx->rstream);
             if (lrc) {
@@ -878,12 +884,17 @@ static int stream_push_resident(aof_ctx *ctx, const uint8_t *frame, aof_flow *fl
         if ((++spins & 0x3FFu) == 0 &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kResidentHostTimeoutS) {
             // no answer: stop it, leave the resident mode and let the caller's frame take the graph path
+            std::fprintf(stderr, "aof: the resident kernel did not answer request %u within %.0f ms (record word %08x, served %u, "
+                                 "on device %u): falling back to one launch per call\n", seq, kResidentHostTimeoutS * 1e3,
+                         (unsigned)*tagged, (unsigned)box->done, (unsigned)box->running);
             resident_stop(ctx);
             ctx->resident_on = false;
             return 0;
         }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     *flow = *ctx->h_flow;
+    flow->count &= 0x00FFFFFFu;
     ctx->cur_slot = slot;
     *served = true;
     return 0;

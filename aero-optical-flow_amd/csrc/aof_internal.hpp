@@ -183,8 +183,9 @@ inline unsigned long long resident_word(uint32_t request, int slot, uint32_t pre
     const unsigned long long prev = prev_request ? (unsigned long long)(prev_request & 0x3FFFFFFFu) + 1ull : 0ull;
     return (unsigned long long)request | ((unsigned long long)(slot & 1) << 32) | (prev << 33);
 }
-int launch_flow_resident(const SmallArgs &a, ResidentBox *box, const uint8_t *frame_a, const uint8_t *frame_b,
-                         uint32_t served, uint64_t idle_ticks, uint64_t life_ticks, void *stream);
+// host_record: the pinned 16-byte record the host polls (top byte of `count` = low byte of the request).
+int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_record, const uint8_t *frame_a,
+                         const uint8_t *frame_b, uint32_t served, uint64_t idle_ticks, uint64_t life_ticks, void *stream);
 int launch_reduce(const ReduceArgs &a, void *stream);
 int launch_derotate(const aof_derotate_params &p, const aof_flow *flows, const aof_gyro *gyro,
                     int64_t n, float *out, void *stream);

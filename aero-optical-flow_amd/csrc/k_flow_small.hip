@@ -196,7 +196,7 @@ __device__ __forceinline__ void run_level(const SearchArgs &a, const FlowTail &t
 // previous call in LDS and fetches only the new one.
 template <bool SUBPIXEL>
 __device__ __forceinline__ void flow_small_pair(const SmallArgs &a, uint32_t pair, const uint8_t *src0, const uint8_t *src1,
-                                                int cur_buf, uint32_t load)
+                                                int cur_buf, uint32_t load, aof_flow *final_copy = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     __shared__ uint32_t s_keys[kThreads];
@@ -299,7 +299,8 @@ __device__ __forceinline__ void flow_small_pair(const SmallArgs &a, uint32_t pai
         m0.px = s_flow1.pred_x;
         m0.py = s_flow1.pred_y;
     }
-    run_level<SUBPIXEL>(a.l0, a.t0, pair, f0[pb], f0[cur_buf], m0, s_keys, s_votes, s_tot, nullptr, two ? &s_flow1 : nullptr);
+    // (final_copy: an LDS copy of the pair's flow record for the caller; visible after its next barrier)
+    run_level<SUBPIXEL>(a.l0, a.t0, pair, f0[pb], f0[cur_buf], m0, s_keys, s_votes, s_tot, final_copy, two ? &s_flow1 : nullptr);
 }
 
 template <bool SUBPIXEL>
@@ -315,17 +316,18 @@ __global__ __launch_bounds__(kThreads) void k_flow_small(SmallArgs a)   // (late
 // through a replayed hipGraph are the runtime's launch and completion, not the 4 us kernel.  Here ONE
 // workgroup stays on the device between calls: the host writes the frame into its pinned ping-pong slot and
 // bumps a request word in pinned memory; lane 0 polls that word, the workgroup computes the pair exactly
-// as k_flow_small does (same function), writes the 16-byte record to pinned memory and then the
-// completion word the host polls.  The kernel ALWAYS ends by itself: after `idle_ticks` of the 100 MHz
+// as k_flow_small does (same function) and publishes the 16-byte record in pinned memory with ONE store,
+// the request's low byte riding in the top byte of `count`, which the host polls for.  The kernel ALWAYS ends by itself: after `idle_ticks` of the 100 MHz
 // real-time counter without a request, after `life_ticks` in total (so that nothing that waits for the
 // device to drain -- a hipFree anywhere in the process -- waits longer than that), or when the host sets
 // the stop word; the next call starts it again.
 template <bool SUBPIXEL>
-__global__ __launch_bounds__(kThreads) void k_flow_resident(SmallArgs a, ResidentBox *box, const uint8_t *frame_a,
-                                                            const uint8_t *frame_b, uint32_t served, uint64_t idle_ticks,
-                                                            uint64_t life_ticks)
+__global__ __launch_bounds__(kThreads) void k_flow_resident(SmallArgs a, ResidentBox *box, aof_flow *host_record,
+                                                            const uint8_t *frame_a, const uint8_t *frame_b, uint32_t served,
+                                                            uint64_t idle_ticks, uint64_t life_ticks)
 {
     __shared__ uint32_t s_req[3];   // request number (0 = leave), slot of the newest frame, buffers to fetch
+    __shared__ aof_flow s_record;   // the call's flow record (the kernel's own copy goes to device memory)
     const uint64_t born = __builtin_amdgcn_s_memrealtime();
     uint64_t idle_since = born;
     uint32_t held[2] = {0u, 0u};    // (thread 0) tag of the request at which LDS buffer b received pinned frame b, 0 = never
@@ -358,10 +360,19 @@ __global__ __launch_bounds__(kThreads) void k_flow_resident(SmallArgs a, Residen
         const uint32_t req = s_req[0], slot = s_req[1], load = s_req[2];
         if (req == 0) break;   // (uniform)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // the host's frame bytes: nothing stale out of L1 / L2
-        flow_small_pair<SUBPIXEL>(a, 0, frame_a, frame_b, (int)slot, load);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // the record before the completion word
+        flow_small_pair<SUBPIXEL>(a, 0, frame_a, frame_b, (int)slot, load, &s_record);
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(&box->done, req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+            // ONE 16-byte store publishes the record: the low byte of the request number rides in the top
+            // byte of `count` (block counts stay below 2^24), the host polls for it and masks it out -- the host
+            // does not wait for a second PCIe write behind a fence.  `done` follows for the next kernel instance
+            // (read only after this one has left).
+            aof_flow r = s_record;
+            r.count = (r.count & 0x00FFFFFFu) | (req << 24);
+            *reinterpret_cast<uint4 *>(host_record) = __builtin_bit_cast(uint4, r);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // pushes the record out (the host is polling for it already)
+            __hip_atomic_store(&box->done, req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         served = req;
         idle_since = __builtin_amdgcn_s_memrealtime();
     }
@@ -402,11 +413,11 @@ bool flow_small_supported(const SmallArgs &a)
     return small_lds_bytes(a) + 4096 <= 160 * 1024;   // frames + the kernel's static arrays
 }
 
-int launch_flow_resident(const SmallArgs &a, ResidentBox *box, const uint8_t *frame_a, const uint8_t *frame_b,
-                         uint32_t served, uint64_t idle_ticks, uint64_t life_ticks, void *stream)
+int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_record, const uint8_t *frame_a,
+                         const uint8_t *frame_b, uint32_t served, uint64_t idle_ticks, uint64_t life_ticks, void *stream)
 {
     if (a.l0.n_pairs != 1 || !flow_small_supported(a)) return (int)hipErrorInvalidValue;
-    void (*fn)(SmallArgs, ResidentBox *, const uint8_t *, const uint8_t *, uint32_t, uint64_t, uint64_t) =
+    void (*fn)(SmallArgs, ResidentBox *, aof_flow *, const uint8_t *, const uint8_t *, uint32_t, uint64_t, uint64_t) =
         a.l0.subpixel ? k_flow_resident<true> : k_flow_resident<false>;
     const size_t lds = small_lds_bytes(a);
     if (lds > 48 * 1024) {
@@ -414,8 +425,8 @@ int launch_flow_resident(const SmallArgs &a, ResidentBox *box, const uint8_t *fr
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(fn, dim3(1), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a, box, frame_a, frame_b, served,
-                       idle_ticks, life_ticks);
+    hipLaunchKernelGGL(fn, dim3(1), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a, box, host_record, frame_a, frame_b,
+                       served, idle_ticks, life_ticks);
     return (int)hipGetLastError();
 }
 

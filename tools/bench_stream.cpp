@@ -43,6 +43,7 @@ int main(int argc, char **argv)
         printf("%dx%d levels=%d %s graph=%d instantiated=%d resident=%d on_device=%d: %.2f us per call (quality %d flow %.3f %.3f)\n",
                w, h, levels, aof_search_variant(ctx), graph, aof_set_stream_graph(ctx, -1), resident,
                aof_set_stream_resident(ctx, -1), us, out.quality, out.flow_x, out.flow_y);
+        fflush(stdout);
         aof_destroy(ctx);
     }
     return 0;

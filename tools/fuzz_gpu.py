@@ -2,7 +2,8 @@
 """Long differential fuzz on a GPU box (not part of the test suite): random geometry, options
 and image statistics; default, in-launch reduction, pruned, generic and separate-kernel device paths against the CPU oracle.
     python tools/fuzz_gpu.py [n_cases] [first_seed]            random configurations, two pairs per call
-    python tools/fuzz_gpu.py [n_cases] [first_seed] many       the persistent coarse kernel: hundreds of pairs per call"""
+    python tools/fuzz_gpu.py [n_cases] [first_seed] many       the persistent coarse kernel: hundreds of pairs per call
+    python tools/fuzz_gpu.py [n_cases] [first_seed] resident   the per-call path served by the resident kernel"""
 import importlib
 import os
 import sys
@@ -131,11 +132,65 @@ def many_pairs(n_cases, seed0):
     print(f"many-pairs fuzz passed: {n_cases} cases of 300..900 pairs per call, {time.time() - t0:.0f} s")
 
 
+def resident(n_cases, seed0):
+    """The per-call path served by the resident kernel (aof_set_stream_resident): random small
+    configurations, sequences of frames pushed one by one with random stream resets, frames that take the
+    launch-per-call path in between, kernel switches and pauses beyond the idle deadline -- every record
+    against the oracle."""
+    t0 = time.time()
+    for s in range(seed0, seed0 + n_cases):
+        rng = np.random.default_rng(330000 + s)
+        kw = small_case(rng)
+        if kw["width"] * kw["height"] > 64 * 1024:   # (the resident path takes frames of at most 64 KB)
+            kw["height"] = max(2 * ((64 * 1024 // kw["width"]) // 2), 36 * (2 if kw["pyramid_levels"] == 2 else 1))
+        p = aof.default_params(**kw)
+        if aof.check_params(p) != 0:
+            continue
+        g0 = aof.grid(p, 0)
+        g1 = aof.grid(p, 1) if p.pyramid_levels == 2 else None
+        if not small_eligible(p, g0, g1) or p.width * p.height > 64 * 1024:
+            continue
+        reach = 9 if p.pyramid_levels == 2 else 4
+        frames, _ = synth.make_sequence(p.width, p.height, 14, reach, seed=s, max_step=reach - 1)
+        po = orc.params_from(p)
+        eng = aof.FlowEngine(p, 0)
+        eng.set_stream_resident(True)
+        prev = None
+        for k in range(14):
+            r = rng.random()
+            if r < 0.08:
+                eng.stream_reset()
+                prev = None
+            elif r < 0.16:
+                eng.set_stream_resident(False)
+            elif r < 0.3:
+                eng.set_stream_resident(True)
+            elif r < 0.34:
+                eng.force_generic(True)
+            elif r < 0.4:
+                eng.force_generic(False)
+            elif r < 0.43:
+                time.sleep(0.07)
+            got = eng.stream_push(frames[k])
+            if prev is None:
+                assert got is None
+            elif got.tobytes() != orc.flow_pair(po, frames[prev], frames[k])["flow"].tobytes():
+                print(f"MISMATCH resident seed {s} frame {k} after {prev}: {kw}", flush=True)
+                sys.exit(1)
+            prev = k
+        eng.close()
+        if (s - seed0 + 1) % 50 == 0:
+            print(f"{s - seed0 + 1} resident cases ok ({time.time() - t0:.0f} s)", flush=True)
+    print(f"resident-kernel fuzz passed: {n_cases} sequences of 14 frames, {time.time() - t0:.0f} s")
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if len(sys.argv) > 3 and sys.argv[3] == "many":
         return many_pairs(n_cases, seed0)
+    if len(sys.argv) > 3 and sys.argv[3] == "resident":
+        return resident(n_cases, seed0)
     dev = torch.device("cuda:0")
     t0, done, skipped, variants = time.time(), 0, 0, {}
     for s in range(seed0, seed0 + n_cases):
