@@ -60,6 +60,7 @@ struct aof_ctx {
     // resident form of the per-call path (aof_set_stream_resident): one workgroup stays on the device
     // and serves aof_stream_push_host through a mailbox in pinned memory
     bool resident_on;
+    bool resident_lost;         // a resident kernel did not leave when asked: what it reads is never freed
     hipStream_t rstream;        // the resident kernel's own stream
     ResidentBox *box;           // pinned, device-visible
     uint32_t rseq;              // number of the last request posted
@@ -366,16 +367,32 @@ constexpr double kResidentHostTimeoutS = 0.25;      // the host gives up on a re
 
 // Asks the resident kernel to leave and waits for it (bounded by the kernel's own deadlines).  Must run
 // before anything that frees or reallocates what the kernel reads, and before a change of kernel choice.
-void resident_stop(aof_ctx *ctx)
+bool resident_stop(aof_ctx *ctx)   // false: it did not leave (never observed; its memory is then leaked, not freed)
 {
-    if (!ctx->box || !ctx->rstream) return;
+    if (!ctx->box || !ctx->rstream) return true;
+    bool left = true;
     const unsigned long long word = __atomic_load_n(&ctx->box->word, __ATOMIC_ACQUIRE);
     if (__atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE)) {
         __atomic_store_n(&ctx->box->word, word | kResidentStopBit, __ATOMIC_RELEASE);
-        (void)hipStreamSynchronize(ctx->rstream);
+        // The kernel clears `running` when it leaves -- at the latest on its 200 ms lifetime deadline.  Wait
+        // for THAT (bounded), and synchronise the stream only once it has happened: a stream
+        // synchronisation has no time limit of its own.
+        (void)hipStreamQuery(ctx->rstream);   // (makes sure the launch has been handed to the device)
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE) &&
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 1.0) {
+        }
+        if (__atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE)) {
+            std::fprintf(stderr, "aof: the resident kernel did not leave within 1 s of being asked to\n");
+            left = false;
+            ctx->resident_lost = true;
+        } else {
+            (void)hipStreamSynchronize(ctx->rstream);
+        }
     }
     __atomic_store_n(&ctx->box->word, word & ~kResidentStopBit, __ATOMIC_RELEASE);
     __atomic_store_n(&ctx->box->running, 0u, __ATOMIC_RELEASE);
+    return left;
 }
 
 }  // namespace
@@ -424,7 +441,12 @@ void aof_destroy(aof_ctx *ctx)
 {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
-    resident_stop(ctx);   // before anything it reads is freed
+    (void)resident_stop(ctx);   // before anything it reads is freed
+    if (ctx->resident_lost) {   // (leak the pinned buffers and the stream rather than free them under a live kernel)
+        ctx->box = nullptr; ctx->rstream = nullptr;
+        ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr;
+        ctx->d_blocks = nullptr; ctx->d_subdirs = nullptr; ctx->d_flow = nullptr; ctx->d_ws = nullptr;
+    }
     if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
     if (ctx->box) (void)hipHostFree(ctx->box);
     if (ctx->ev) {
@@ -477,7 +499,7 @@ const char *aof_search_variant(const aof_ctx *ctx)
 int aof_set_force_generic(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
-    { DeviceGuard guard(ctx->device); resident_stop(ctx); }   // it runs the kernels chosen so far
+    { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }   // it runs the kernels chosen so far
     if ((on != 0) != ctx->force_generic)   // captured graphs hold the old kernels
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
@@ -488,7 +510,7 @@ int aof_set_force_generic(aof_ctx *ctx, int on)
 int aof_set_search_mode(aof_ctx *ctx, int mode)
 {
     if (!ctx || mode < AOF_SEARCH_EXHAUSTIVE || mode > AOF_SEARCH_PRUNED) return -EINVAL;
-    { DeviceGuard guard(ctx->device); resident_stop(ctx); }   // it runs the kernels chosen so far
+    { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }   // it runs the kernels chosen so far
     if (mode != ctx->search_mode) {  // captured graphs hold the old kernel
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
@@ -597,7 +619,7 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
 int aof_set_split_coarse(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
-    { DeviceGuard guard(ctx->device); resident_stop(ctx); }   // it runs the kernels chosen so far
+    { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }   // it runs the kernels chosen so far
     if ((on != 0) != ctx->split_coarse)   // captured graphs hold the old kernels
         for (int i = 0; i < 2; i++)
             if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
@@ -642,7 +664,11 @@ int aof_derotate_batch_device(const aof_derotate_params *p, const aof_flow *d_fl
 
 static void free_host_state(aof_ctx *ctx)
 {
-    resident_stop(ctx);
+    (void)resident_stop(ctx);
+    if (ctx->resident_lost) {
+        ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr;
+        ctx->d_blocks = nullptr; ctx->d_subdirs = nullptr; ctx->d_flow = nullptr; ctx->d_ws = nullptr;
+    }
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); ctx->stream = nullptr; }
     if (ctx->h_frame) { (void)hipHostFree(ctx->h_frame); ctx->h_frame = nullptr; }
     for (int i = 0; i < 2; i++) if (ctx->h_frames[i]) { (void)hipHostFree(ctx->h_frames[i]); ctx->h_frames[i] = nullptr; }
@@ -887,7 +913,7 @@ static int stream_push_resident(aof_ctx *ctx, const uint8_t *frame, aof_flow *fl
             std::fprintf(stderr, "aof: the resident kernel did not answer request %u within %.0f ms (record word %08x, served %u, "
                                  "on device %u): falling back to one launch per call\n", seq, kResidentHostTimeoutS * 1e3,
                          (unsigned)*tagged, (unsigned)box->done, (unsigned)box->running);
-            resident_stop(ctx);
+            (void)resident_stop(ctx);
             ctx->resident_on = false;
             return 0;
         }
@@ -904,7 +930,7 @@ int aof_set_stream_resident(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
     if (on < 0) return (ctx->box && __atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE)) ? 1 : 0;
-    if (!on) { DeviceGuard guard(ctx->device); resident_stop(ctx); }
+    if (!on) { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }
     ctx->resident_on = on != 0;
     return 0;
 }

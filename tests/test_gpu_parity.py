@@ -1136,6 +1136,7 @@ def test_streaming_graph_and_eager_paths_agree(aof, orc, synth, gpu_device, kw):
 @pytest.mark.parametrize("kw", [dict(px4=1), dict(px4=1, pyramid_levels=2, mean_subtract=1),
                                 dict(px4=1, size=(128, 128), pyramid_levels=2, mean_subtract=1),
                                 dict(size=(128, 96), mean_subtract=1), dict(px4=1, size=(96, 80), subpixel=0, hist_filter=0)])
+@pytest.mark.timeout(120)
 def test_resident_kernel_serves_the_streaming_entry_point(aof, orc, synth, gpu_device, kw):
     """aof_set_stream_resident: ONE workgroup stays on the device and takes the frames through a mailbox
     in pinned memory.  Every record must equal the oracle's (and hence the launch-per-call paths'):
