@@ -26,10 +26,7 @@ namespace aof {
 namespace {
 
 constexpr int kThreads = 256;
-#ifndef AOF_INGEST_ROWS
-#define AOF_INGEST_ROWS 128
-#endif
-constexpr int kRowsPerBlock = AOF_INGEST_ROWS;
+constexpr int kRowsPerBlock = 128;   // (64 / 32 rows per workgroup: 80 / 115 us instead of 68 -- the table and the flush do not amortise)
 constexpr int kLaneField = 6;      // bits per counter of a lane's table sums: <= 3 pieces x 16 pixels = 48 < 64
 constexpr int kLanePieces = 3;     // pieces between two widenings
 constexpr int kWavePieces = 63;    // pieces per lane between two wave sums: 63 x 16 x 64 lanes = 64 512 < 65 536

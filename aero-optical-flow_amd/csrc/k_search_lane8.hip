@@ -229,12 +229,10 @@ int for_slices(const SearchArgs &a, F &&launch)
 // Workgroup size of the flat kernels.  Large launches: 64, 128 and 256 threads measure the same (512 is
 // 4 % slower).  A launch of only a few generations of waves (configs[3]'s per-GPU share: 128 VGA pairs
 // are 2.3 generations) ends sooner with one-wave workgroups, whose slots free up wave by wave.
-#ifndef AOF_LANE8_SMALL_THREADS
-#define AOF_LANE8_SMALL_THREADS 64
-#endif
+constexpr int kSmallLaunchThreads = 64;
 static int flat_threads(int64_t items)
 {
-    return items < 6 * 256 * 1024 ? AOF_LANE8_SMALL_THREADS : kThreads;   // fewer than six generations of 256 CUs x 16 waves
+    return items < 6 * 256 * 1024 ? kSmallLaunchThreads : kThreads;   // fewer than six generations of 256 CUs x 16 waves
 }
 
 bool lane8_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t capacity_pairs)
