@@ -47,8 +47,8 @@ for wl in $WL; do
         trace share_p128 --pairs 128 --steps 200
         echo "share done";;
     lanes)
-        for w2 in c2 c3 c2h c1b; do
-            line lanes_$w2 --workload $w2 $(args_of $w2) --streams 2 --cpu-seconds 0
+        for w2 in c2 c3 c2h c1b c5 c5h; do
+            line lanes_$w2 --workload $w2 $(args_of $w2) --streams 2 --reduce auto --cpu-seconds 0
         done
         line lanes_c3_p512 --workload c3 --pairs 512 --streams 2 --cpu-seconds 0
         echo "lanes done";;
