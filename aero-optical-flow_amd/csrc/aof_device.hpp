@@ -152,7 +152,7 @@ __device__ __forceinline__ void wave_vote2(uint32_t *hist_x, uint32_t *hist_y, i
 
 // Bijective XCD-aware remap of a 1-D grid (workgroups b and b+8 share an XCD's
 // L2 under round-robin placement): XCD k gets one contiguous chunk of logical
-// ids, so consecutive strips of one frame pair are staged through the same L2.
+// ids, so consecutive block rows of one frame pair are served by the same L2.
 // Placement only affects speed, never results.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total)
 {
