@@ -53,7 +53,9 @@ struct aof_ctx {
     uint8_t *h_frames[2];       // small frames: pinned ping-pong frames the kernels read in place
     bool zero_copy;             // (no H2D copy: a 64x64 frame is 4 KB over PCIe)
     aof_flow *h_flow;           // pinned result
+    uint32_t *h_tag;            // pinned (same allocation, its own cache line): the tag the next tagged record carries
     hipGraphExec_t push_graph[2];
+    bool push_tagged[2];        // the slot's graph publishes a tagged record: the host polls for it, no stream wait
     bool graph_disabled;        // capture failed once: stay on the plain path
     bool capturing;
     bool split_coarse;          // run K1 / level-1 search / level-1 reduce as separate kernels
@@ -363,6 +365,7 @@ bool small_args(const aof_ctx *ctx, const BatchView &v, int64_t n_pairs, SmallAr
 // ---- resident form of the per-call path ----
 constexpr uint64_t kResidentIdleTicks = 5000000;    // 50 ms of the 100 MHz counter without a request: the kernel leaves
 constexpr uint64_t kResidentLifeTicks = 20000000;   // 200 ms in total: nothing that waits for the device waits longer
+constexpr double kTaggedRecordWaitS = 0.002;         // per-call graph: polling for the tagged record this long, then the stream decides
 constexpr double kResidentHostTimeoutS = 0.25;      // the host gives up on a request and falls back to the graph path
 
 // Asks the resident kernel to leave and waits for it (bounded by the kernel's own deadlines).  Must run
@@ -444,7 +447,7 @@ void aof_destroy(aof_ctx *ctx)
     (void)resident_stop(ctx);   // before anything it reads is freed
     if (ctx->resident_lost) {   // (leak the pinned buffers and the stream rather than free them under a live kernel)
         ctx->box = nullptr; ctx->rstream = nullptr;
-        ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr;
+        ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr; ctx->h_tag = nullptr;
         ctx->d_blocks = nullptr; ctx->d_subdirs = nullptr; ctx->d_flow = nullptr; ctx->d_ws = nullptr;
     }
     if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
@@ -496,13 +499,22 @@ const char *aof_search_variant(const aof_ctx *ctx)
     }
 }
 
+// Captured graphs hold the kernels chosen so far.  (The per-call path does not wait for the stream after a
+// tagged record has arrived: drain it before a graph goes.)
+static void drop_push_graphs(aof_ctx *ctx)
+{
+    if (!ctx->push_graph[0] && !ctx->push_graph[1]) return;
+    DeviceGuard guard(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; i++)
+        if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
+}
+
 int aof_set_force_generic(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
     { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }   // it runs the kernels chosen so far
-    if ((on != 0) != ctx->force_generic)   // captured graphs hold the old kernels
-        for (int i = 0; i < 2; i++)
-            if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
+    if ((on != 0) != ctx->force_generic) drop_push_graphs(ctx);
     ctx->force_generic = on != 0;
     return 0;
 }
@@ -511,10 +523,7 @@ int aof_set_search_mode(aof_ctx *ctx, int mode)
 {
     if (!ctx || mode < AOF_SEARCH_EXHAUSTIVE || mode > AOF_SEARCH_PRUNED) return -EINVAL;
     { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }   // it runs the kernels chosen so far
-    if (mode != ctx->search_mode) {  // captured graphs hold the old kernel
-        for (int i = 0; i < 2; i++)
-            if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
-    }
+    if (mode != ctx->search_mode) drop_push_graphs(ctx);
     ctx->search_mode = mode;
     return 0;
 }
@@ -620,9 +629,7 @@ int aof_set_split_coarse(aof_ctx *ctx, int on)
 {
     if (!ctx) return -EINVAL;
     { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }   // it runs the kernels chosen so far
-    if ((on != 0) != ctx->split_coarse)   // captured graphs hold the old kernels
-        for (int i = 0; i < 2; i++)
-            if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
+    if ((on != 0) != ctx->split_coarse) drop_push_graphs(ctx);
     ctx->split_coarse = on != 0;
     return 0;
 }
@@ -666,13 +673,13 @@ static void free_host_state(aof_ctx *ctx)
 {
     (void)resident_stop(ctx);
     if (ctx->resident_lost) {
-        ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr;
+        ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr; ctx->h_tag = nullptr;
         ctx->d_blocks = nullptr; ctx->d_subdirs = nullptr; ctx->d_flow = nullptr; ctx->d_ws = nullptr;
     }
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); ctx->stream = nullptr; }
     if (ctx->h_frame) { (void)hipHostFree(ctx->h_frame); ctx->h_frame = nullptr; }
     for (int i = 0; i < 2; i++) if (ctx->h_frames[i]) { (void)hipHostFree(ctx->h_frames[i]); ctx->h_frames[i] = nullptr; }
-    if (ctx->h_flow) { (void)hipHostFree(ctx->h_flow); ctx->h_flow = nullptr; }
+    if (ctx->h_flow) { (void)hipHostFree(ctx->h_flow); ctx->h_flow = nullptr; ctx->h_tag = nullptr; }
     for (int i = 0; i < 2; i++) if (ctx->d_frames[i]) { (void)hipFree(ctx->d_frames[i]); ctx->d_frames[i] = nullptr; }
     for (int i = 0; i < 2; i++) if (ctx->d_pair[i]) { (void)hipFree(ctx->d_pair[i]); ctx->d_pair[i] = nullptr; }
     if (ctx->d_blocks) { (void)hipFree(ctx->d_blocks); ctx->d_blocks = nullptr; }
@@ -704,7 +711,10 @@ static int alloc_host_state(aof_ctx *ctx)
     if (ctx->zero_copy)
         for (int i = 0; i < 2; i++)
             HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_frames[i], frame, hipHostMallocMapped | hipHostMallocCoherent));
-    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_flow, sizeof(aof_flow), hipHostMallocMapped | hipHostMallocCoherent));
+    // (record in the first cache line, the tag of the next tagged record in the second)
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_flow, 128, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(ctx->h_flow, 0, 128);
+    ctx->h_tag = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->h_flow) + 64);
     return 0;
 }
 
@@ -737,17 +747,34 @@ static void build_push_graph(aof_ctx *ctx, int slot)
     }
     ctx->capturing = true;
     uint8_t *const *frames = ctx->zero_copy ? ctx->h_frames : ctx->d_frames;
-    bool ok = ctx->zero_copy ||
-              hipMemcpyAsync(ctx->d_frames[slot], ctx->h_frame, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-    // K3 writes the 16-byte result straight into the pinned (device-visible, coherent) host
-    // record: no D2H copy node; it is visible to the host once the stream has drained.
-    ok = ok && aof_flow_batch_device(ctx, frames[1 - slot], frames[slot], (int64_t)bytes, 1,
-                                     ctx->d_blocks, ctx->d_subdirs, ctx->h_flow, ctx->d_ws, ctx->ws_bytes,
-                                     ctx->stream) == 0;
+    bool ok = false, tagged = false;
+    if (ctx->zero_copy) {
+        // small frames served by the one-workgroup kernel: the record comes tagged (stream_push_graph polls
+        // for it); the kernel's own copy goes to device memory
+        aof_ws_layout L;
+        aof_workspace_layout(&p, 1, &L);
+        const BatchView v = batch_view(ctx, L, frames[1 - slot], frames[slot], (int64_t)bytes, ctx->d_blocks, ctx->d_subdirs,
+                                       ctx->d_flow, ctx->d_ws);
+        SmallArgs sm;
+        if (small_args(ctx, v, 1, &sm)) {
+            tagged = true;
+            ok = launch_flow_small_tagged(sm, ctx->h_flow, ctx->h_tag, ctx->stream) == 0;
+        }
+    }
+    if (!tagged) {
+        ok = ctx->zero_copy ||
+             hipMemcpyAsync(ctx->d_frames[slot], ctx->h_frame, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+        // K3 writes the 16-byte result straight into the pinned (device-visible, coherent) host
+        // record: no D2H copy node; it is visible to the host once the stream has drained.
+        ok = ok && aof_flow_batch_device(ctx, frames[1 - slot], frames[slot], (int64_t)bytes, 1,
+                                         ctx->d_blocks, ctx->d_subdirs, ctx->h_flow, ctx->d_ws, ctx->ws_bytes,
+                                         ctx->stream) == 0;
+    }
     ctx->capturing = false;
     const bool ended = hipStreamEndCapture(ctx->stream, &graph) == hipSuccess && graph;
     if (ok && ended && hipGraphInstantiate(&ctx->push_graph[slot], graph, nullptr, nullptr, 0) == hipSuccess) {
         (void)hipGraphDestroy(graph);
+        ctx->push_tagged[slot] = tagged;
         return;
     }
     if (graph) (void)hipGraphDestroy(graph);
@@ -841,13 +868,39 @@ static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow,
     ctx->rframe_req[slot] = 0;   // (written outside a resident request)
     std::memcpy(ctx->zero_copy ? ctx->h_frames[slot] : ctx->h_frame, frame,
                 (size_t)ctx->params.width * ctx->params.height);
+    const bool tagged = ctx->push_tagged[slot];
+    volatile uint32_t *word = &reinterpret_cast<volatile uint32_t *>(ctx->h_flow)[2];
+    uint32_t tag = 0;
+    if (tagged) {
+        tag = ++ctx->rseq << 24;
+        if ((*word & 0xFF000000u) == tag) *word ^= 0x80000000u;   // (first use, or a record of another path: make its tag differ)
+        __atomic_store_n(ctx->h_tag, ctx->rseq, __ATOMIC_RELEASE);
+    }
     hipError_t e = hipGraphLaunch(ctx->push_graph[slot], ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && tagged) {
+        // The record arrives as ONE 16-byte store with the tag in the top byte of `count`: the kernel is
+        // through with both frames when it is there, and the runtime's own completion path (longer than
+        // the kernel) is not waited for.  A record that stays away is left to the stream: it drains or
+        // reports the fault.
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 1; (*word & 0xFF000000u) != tag; spins++) {
+            if ((spins & 0x3FFu) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kTaggedRecordWaitS) {
+                e = hipStreamSynchronize(ctx->stream);
+                if (e == hipSuccess && (*word & 0xFF000000u) != tag) e = hipErrorUnknown;
+                break;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else if (e == hipSuccess) {
+        e = hipStreamSynchronize(ctx->stream);
+    }
     if (e != hipSuccess) {
         ctx->have_prev = false;
         return fail(ctx, -EIO, "graph replay: %s", hipGetErrorString(e));
     }
     *flow = *ctx->h_flow;
+    if (tagged) flow->count &= 0x00FFFFFFu;
     ctx->cur_slot = slot;
     return 0;
 }

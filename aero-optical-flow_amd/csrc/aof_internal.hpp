@@ -163,6 +163,9 @@ int launch_search_tile16(const SearchArgs &a, void *stream);
 // Small pairs (frames fit LDS, grids <= 256 blocks), one or two levels, in one launch: one workgroup per pair.
 bool flow_small_supported(const SmallArgs &a);
 int launch_flow_small(const SmallArgs &a, void *stream);
+// One pair, the record published in pinned host memory by ONE tagged 16-byte store (top byte of `count` =
+// low byte of *tag, which the host wrote before the launch): the per-call path polls for it.
+int launch_flow_small_tagged(const SmallArgs &a, aof_flow *host_record, const uint32_t *tag, void *stream);
 // The resident form of the same kernel for the per-call path: one workgroup that stays on the device and
 // serves requests posted through a mailbox in pinned host memory (k_flow_small.hip).
 struct ResidentBox {

@@ -311,6 +311,25 @@ __global__ __launch_bounds__(kThreads) void k_flow_small(SmallArgs a)   // (late
                               1, 3u);
 }
 
+// The per-call path (one pair per launch, record in pinned host memory): the record leaves with ONE 16-byte
+// store whose `count` carries the low byte of *tag in its top byte (block counts stay below 2^24) -- the
+// host, which wrote the tag before the launch, polls the record for it instead of waiting for the stream
+// to drain (the runtime's completion path costs more than the kernel).
+template <bool SUBPIXEL>
+__global__ __launch_bounds__(kThreads) void k_flow_small_tagged(SmallArgs a, aof_flow *host_record, const uint32_t *tag)
+{
+    __shared__ aof_flow s_record;
+    uint32_t t = 0;
+    if (threadIdx.x == 0) t = __hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (in flight beside the frames)
+    flow_small_pair<SUBPIXEL>(a, 0, a.l0.prev, a.l0.cur, 1, 3u, &s_record);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        aof_flow r = s_record;
+        r.count = (r.count & 0x00FFFFFFu) | (t << 24);
+        *reinterpret_cast<uint4 *>(host_record) = __builtin_bit_cast(uint4, r);
+    }
+}
+
 // ---- the resident form of the per-call path (aof_set_stream_resident) --------------------------------
 // calcFlow() hands over ONE small frame per call (mainloop.cpp:322), and 20 of the 25 us such a call takes
 // through a replayed hipGraph are the runtime's launch and completion, not the 4 us kernel.  Here ONE
@@ -427,6 +446,20 @@ int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_re
     }
     hipLaunchKernelGGL(fn, dim3(1), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a, box, host_record, frame_a, frame_b,
                        served, idle_ticks, life_ticks);
+    return (int)hipGetLastError();
+}
+
+int launch_flow_small_tagged(const SmallArgs &a, aof_flow *host_record, const uint32_t *tag, void *stream)
+{
+    if (a.l0.n_pairs != 1 || !flow_small_supported(a) || !host_record || !tag) return (int)hipErrorInvalidValue;
+    void (*fn)(SmallArgs, aof_flow *, const uint32_t *) = a.l0.subpixel ? k_flow_small_tagged<true> : k_flow_small_tagged<false>;
+    const size_t lds = small_lds_bytes(a);
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(fn, dim3(1), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a, host_record, tag);
     return (int)hipGetLastError();
 }
 

@@ -181,8 +181,8 @@ int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, ao
 int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow);
 int aof_stream_reset(aof_ctx *ctx);
 /* Opt-in resident form of the streaming entry point for small frames (the one-workgroup kernel's class:
- * 8x8 tiles, grids of 8..256 blocks, frames of at most 64 KB).  20 of the 25 us a call takes through a
- * replayed hipGraph are the runtime's launch and completion; with on = 1 ONE workgroup stays on the device
+ * 8x8 tiles, grids of 8..256 blocks, frames of at most 64 KB).  Most of the 14 us a call takes through a
+ * replayed hipGraph is the launch; with on = 1 ONE workgroup stays on the device
  * between calls, polls a request word in pinned host memory, computes the pair exactly as the one-launch
  * kernel does and posts the 16-byte record and a completion word the host polls -- no launch per frame.
  * The kernel always ends by itself: after 50 ms without a request, after 200 ms in total (so nothing that
@@ -191,9 +191,12 @@ int aof_stream_reset(aof_ctx *ctx);
  * request that is not answered within 250 ms stops it for good and the call falls back to the graph path.
  * Results are bit-identical in both forms.  on < 0 queries whether the kernel is on the device now. */
 int aof_set_stream_resident(aof_ctx *ctx, int on);
-/* The streaming entry point replays a captured hipGraph (H2D frame, kernels, D2H result)
- * per call; this switches the capture off (1 = on, the default).  Returns whether a graph
- * is currently instantiated for the next call when on < 0 (query). */
+/* The streaming entry point replays a captured hipGraph per call (H2D frame, kernels, the result
+ * written into pinned host memory; for frames of at most 64 KB served by the one-workgroup kernel:
+ * that ONE kernel reading the pinned frames in place and publishing the record with a tag the host
+ * polls for, without waiting for the stream); this switches the capture off (1 = on, the default:
+ * eager launches and a stream wait otherwise).  Returns whether a graph is currently instantiated
+ * for the next call when on < 0 (query). */
 int aof_set_stream_graph(aof_ctx *ctx, int on);
 
 /* ---- frame ingest: the caller-side steps the reference runs on

@@ -1133,6 +1133,40 @@ def test_streaming_graph_and_eager_paths_agree(aof, orc, synth, gpu_device, kw):
         assert outs[0][k - 1] == orc.flow_pair(po, frames[k - 1], frames[k])["flow"].tobytes()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(pyramid_levels=2, mean_subtract=1)])
+def test_per_call_graph_polls_a_tagged_record(aof, orc, synth, gpu_device, kw):
+    """Small frames: the replayed graph is ONE kernel that publishes the 16-byte record in pinned memory with
+    a tag in the top byte of `count`, and the host polls for the tag instead of waiting for the stream.
+    600 calls take the tag through its 256 values twice; `count` must come back without it, calls through
+    the other host entry point (which share the stream and the pinned record) may come in between, and a
+    context destroyed right after a call must not trip over a launch the runtime has not retired yet."""
+    p = aof.px4flow_params(64, 64, **kw)
+    frames, _ = synth.make_sequence(64, 64, 7, 4, seed=77, max_step=3)
+    po = orc.params_from(p)
+    want = {}
+    eng = aof.FlowEngine(p, 0)
+    assert eng.stream_push(frames[0]) is None
+    prev = 0
+    for call in range(600):
+        k = (prev + 1 + call % 3) % 7
+        if (prev, k) not in want:
+            want[(prev, k)] = orc.flow_pair(po, frames[prev], frames[k])["flow"]
+        got = eng.stream_push(frames[k])
+        assert got.tobytes() == want[(prev, k)].tobytes(), (call, prev, k)
+        assert int(got["count"]) < (1 << 24)
+        prev = k
+        if call % 97 == 5:
+            _, _, pair = eng.flow_pair_host(frames[1], frames[2])
+            assert pair.tobytes() == orc.flow_pair(po, frames[1], frames[2])["flow"].tobytes()
+    assert eng.stream_graph_active()
+    eng.close()
+    for _ in range(3):   # destroyed with the last launch barely retired
+        e2 = aof.FlowEngine(p, 0)
+        e2.stream_push(frames[0])
+        e2.stream_push(frames[1])
+        e2.close()
+
+
 @pytest.mark.parametrize("kw", [dict(px4=1), dict(px4=1, pyramid_levels=2, mean_subtract=1),
                                 dict(px4=1, size=(128, 128), pyramid_levels=2, mean_subtract=1),
                                 dict(size=(128, 96), mean_subtract=1), dict(px4=1, size=(96, 80), subpixel=0, hist_filter=0)])

@@ -7,9 +7,10 @@
 #include "aof.h"
 int main(int argc, char **argv)
 {
-    const int w = argc > 1 ? atoi(argv[1]) : 64, h = argc > 2 ? atoi(argv[2]) : 64, calls = 5000;
+    const int w = argc > 1 ? atoi(argv[1]) : 64, h = argc > 2 ? atoi(argv[2]) : 64;
     const int levels = argc > 3 ? atoi(argv[3]) : 1;   // 2: what OpticalFlowOpenCV ships (two levels + mean equalisation)
     const int only = argc > 4 ? atoi(argv[4]) : -1;    // run one mode only (1 = lane8 without the graph: rocprofv3 cannot trace graph launches)
+    const int calls = argc > 5 ? atoi(argv[5]) : 5000;   // (a long run shows whether the per-call cost creeps: the tagged path never waits for the stream)
     aof_params p;
     aof_params_px4flow(&p, w, h, 4, 30, 3000);
     if (levels == 2) { p.pyramid_levels = 2; p.mean_subtract = 1; }

@@ -22,8 +22,10 @@ for f in sorted(glob.glob(os.path.join(ev, "pmc_*.txt"))):
 lat = os.path.join(ev, "stream_latency.txt")
 if os.path.exists(lat):
     head = ("# tools/stream_latency.sh (tools/bench_stream.cpp): microseconds per aof_stream_push_host call from C++, 5000 calls after 50\n"
-            "# warm-up calls.  graph=1: one replayed hipGraph per call; resident=1: aof_set_stream_resident, a one-workgroup kernel stays\n"
-            "# on the device and serves the calls through a mailbox in pinned memory (no launch per call).\n")
+            "# warm-up calls.  graph=1: one replayed hipGraph per call (lane8 rows: ONE kernel whose record arrives tagged in pinned memory,\n"
+            "# the host polls for the tag instead of waiting for the stream); graph=0: eager launches + stream wait; resident=1:\n"
+            "# aof_set_stream_resident, a one-workgroup kernel stays on the device and serves the calls through a mailbox in pinned\n"
+            "# memory (no launch per call).\n")
     open(os.path.join(prof, f"{prefix.split('_')[0]}_stream_latency.txt"), "w").write(head + open(lat).read()); n += 1
 src = os.path.join(ev, "pmc_traffic.json")
 if os.path.exists(src):
