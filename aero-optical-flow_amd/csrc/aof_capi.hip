@@ -537,7 +537,10 @@ int aof_set_profiling(aof_ctx *ctx, int on)
         if (!ctx->ev) return fail(ctx, -ENOMEM, "event ring");
         for (int k = 0; k < AOF_K_COUNT; k++)
             for (int r = 0; r < AOF_PROFILE_RING; r++)
-                for (int e = 0; e < 2; e++) HIP_TRY(ctx, hipEventCreate(&ctx->ev[k][r][e]));
+                // timing only: without the system-scope fence a default event performs when it is
+                // recorded (an L2 write-back and invalidation between the kernels it brackets)
+                for (int e = 0; e < 2; e++)
+                    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev[k][r][e], hipEventDisableSystemFence));
     }
     ctx->profiling = on != 0;
     ctx->profile_mask = 0xFFFFFFFFu;
