@@ -3,7 +3,7 @@
 and image statistics; default, in-launch reduction, pruned, generic and separate-kernel device paths against the CPU oracle.
     python tools/fuzz_gpu.py [n_cases] [first_seed]            random configurations, two pairs per call
     python tools/fuzz_gpu.py [n_cases] [first_seed] many       the persistent coarse kernel: hundreds of pairs per call
-    python tools/fuzz_gpu.py [n_cases] [first_seed] resident   the per-call path served by the resident kernel"""
+    python tools/fuzz_gpu.py [n_cases] [first_seed] resident   the per-call path: resident kernel, tagged graph, eager launches"""
 import importlib
 import os
 import sys
@@ -154,10 +154,17 @@ def resident(n_cases, seed0):
         frames, _ = synth.make_sequence(p.width, p.height, 14, reach, seed=s, max_step=reach - 1)
         po = orc.params_from(p)
         eng = aof.FlowEngine(p, 0)
-        eng.set_stream_resident(True)
+        eng.set_stream_resident(bool(rng.random() < 0.6))   # (off: the replayed graph whose tagged record the host polls for)
         prev = None
         for k in range(14):
             r = rng.random()
+            if rng.random() < 0.06:
+                eng.set_stream_graph(bool(rng.random() < 0.5))   # eager launches + stream wait / the graph again
+            if rng.random() < 0.05 and k >= 2:   # the other host entry point shares the stream and the pinned record
+                _, _, pair = eng.flow_pair_host(frames[k - 2], frames[k - 1])
+                if pair.tobytes() != orc.flow_pair(po, frames[k - 2], frames[k - 1])["flow"].tobytes():
+                    print(f"MISMATCH pair entry point seed {s} frame {k}: {kw}", flush=True)
+                    sys.exit(1)
             if r < 0.08:
                 eng.stream_reset()
                 prev = None
@@ -181,7 +188,7 @@ def resident(n_cases, seed0):
         eng.close()
         if (s - seed0 + 1) % 50 == 0:
             print(f"{s - seed0 + 1} resident cases ok ({time.time() - t0:.0f} s)", flush=True)
-    print(f"resident-kernel fuzz passed: {n_cases} sequences of 14 frames, {time.time() - t0:.0f} s")
+    print(f"per-call fuzz passed: {n_cases} sequences of 14 frames, {time.time() - t0:.0f} s")
 
 
 def main():
