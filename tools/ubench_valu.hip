@@ -27,6 +27,20 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *clk)
         if (OP == 7) asm volatile(REP8("v_and_or_b32 %0, %0, %8, %9\n v_and_or_b32 %1, %1, %8, %9\n v_and_or_b32 %2, %2, %8, %9\n v_and_or_b32 %3, %3, %8, %9\n") : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));
         if (OP == 8) asm volatile(REP8("v_mqsad_u32_u8 %0, %1, %2, %0\n") : "+v"(*(__uint128_t *)&q0) : "v"(src), "v"(b));
         if (OP == 9) asm volatile(REP8("v_sad_u16 %0, %8, %9, %0\n v_sad_u16 %1, %8, %9, %1\n v_sad_u16 %2, %8, %9, %2\n v_sad_u16 %3, %8, %9, %3\n") : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));
+#define OP3(N, NAME) if (OP == N) asm volatile(REP8(NAME " %0, %8, %9, %0\n " NAME " %1, %8, %9, %1\n " NAME " %2, %8, %9, %2\n " NAME " %3, %8, %9, %3\n") : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));
+#define OP2(N, NAME) if (OP == N) asm volatile(REP8(NAME " %0, %8, %0\n " NAME " %1, %9, %1\n " NAME " %2, %8, %2\n " NAME " %3, %9, %3\n") : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));
+        OP3(10, "v_lerp_u8")
+        OP3(11, "v_alignbyte_b32")
+        OP3(12, "v_perm_b32")
+        OP2(13, "v_and_b32")
+        OP2(14, "v_xor_b32")
+        OP2(15, "v_lshrrev_b32")
+        OP2(16, "v_min_u32")
+        OP2(17, "v_pk_add_u16")
+        OP3(18, "v_bfe_u32")
+        OP3(19, "v_add3_u32")
+        OP3(20, "v_xad_u32")
+        OP2(21, "v_sub_u32")
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (unsigned)(q0 + q1 + q2 + q3);
@@ -69,5 +83,17 @@ int main()
     run<9>("v_sad_u16", 32, d_out, d_clk);
     run<1>("v_qsad_pk_u16_u8", 32, d_out, d_clk);
     run<8>("v_mqsad_u32_u8", 8, d_out, d_clk);
+    run<10>("v_lerp_u8", 32, d_out, d_clk);
+    run<11>("v_alignbyte_b32", 32, d_out, d_clk);
+    run<12>("v_perm_b32", 32, d_out, d_clk);
+    run<13>("v_and_b32", 32, d_out, d_clk);
+    run<14>("v_xor_b32", 32, d_out, d_clk);
+    run<15>("v_lshrrev_b32", 32, d_out, d_clk);
+    run<16>("v_min_u32", 32, d_out, d_clk);
+    run<17>("v_pk_add_u16", 32, d_out, d_clk);
+    run<18>("v_bfe_u32", 32, d_out, d_clk);
+    run<19>("v_add3_u32", 32, d_out, d_clk);
+    run<20>("v_xad_u32", 32, d_out, d_clk);
+    run<21>("v_sub_u32", 32, d_out, d_clk);
     return 0;
 }
