@@ -170,8 +170,8 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
     *reduced = false;
     switch (search_kind(ctx, a)) {
     case SK_TILE16:
-        rc = launch_search_tile16(a, s);
-        if (!rc && a.subpixel) rc = launch_refine(a, s);
+        rc = launch_search_tile16(a, s);   // (refines out of its LDS tile when directions are wanted)
+        if (!rc && a.subpixel && !tile16_refines(a)) rc = launch_refine(a, s);
         break;
     case SK_LANE8_GROUP:   // refines in the same lane and finalises the flow records
         rc = launch_flow_lane8(a, tail, s);

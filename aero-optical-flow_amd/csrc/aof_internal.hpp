@@ -159,6 +159,7 @@ int lane8_group(const SearchArgs &a);  // pairs per workgroup, 0 = not applicabl
 int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream);
 // LDS-tiled (block, dy)-per-lane kernel for B=16, S=8 on a dense grid (any predictor).
 bool tile16_supported(const SearchArgs &a);
+bool tile16_refines(const SearchArgs &a);   // the launch also writes the half-pixel directions (no K2b behind it)
 int launch_search_tile16(const SearchArgs &a, void *stream);
 // Small pairs (frames fit LDS, grids <= 256 blocks), one or two levels, in one launch: one workgroup per pair.
 bool flow_small_supported(const SmallArgs &a);

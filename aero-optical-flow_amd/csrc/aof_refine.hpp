@@ -19,8 +19,9 @@
 
 namespace aof {
 
-// Running state of one block's refinement: feed rows y = -1, 0, ..., B in order.
-template <int NW>  // dwords per tile row: 2 (8x8) or 4 (16x16)
+// Running state of one block's refinement: feed rows y = -1, 0, ..., B in order (a slice of ROWS
+// tile rows: its rows -1 .. ROWS; the direction sums of the slices of a block add up).
+template <int NW, int ROWS = 4 * NW>  // dwords per tile row: 2 (8x8) or 4 (16x16); tile rows fed (a slice when lanes share a block)
 struct RefineState {
     uint32_t acc[8];
     uint32_t pc[NW], ph[NW], pl[NW];  // previous window row: C, H+, H-
@@ -31,12 +32,13 @@ struct RefineState {
         for (int k = 0; k < 8; k++) acc[k] = 0;
     }
 
-    // d: bytes -1 .. B+1 of window row Y relative to the best match (d[NW]: only its two low
-    // bytes are used); ref: the reference tile.  Y is a compile-time constant at every call.
+    // d: bytes -1 .. 4 NW + 1 of window row Y relative to the best match (d[NW]: only its two low
+    // bytes are used); ref: the reference tile rows of the slice.  Y is a compile-time constant
+    // at every call.
     template <int Y>
-    __device__ __forceinline__ void row(const uint32_t (&d)[NW + 1], const uint32_t (&ref)[4 * NW][NW])
+    __device__ __forceinline__ void row(const uint32_t (&d)[NW + 1], const uint32_t (&ref)[ROWS][NW])
     {
-        constexpr int B = 4 * NW;
+        constexpr int B = ROWS;
         uint32_t c[NW], hp[NW], hm[NW];
 #pragma unroll
         for (int q = 0; q < NW; q++) {

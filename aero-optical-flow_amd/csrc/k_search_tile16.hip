@@ -14,14 +14,18 @@
 // minimum in scan order wins" exactly (16x16 max SAD 65 280 fits 16 bits, idx < 289).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
+#include "aof_refine.hpp"
 
 namespace aof {
+
+bool tile16_refines(const SearchArgs &a);
 
 namespace {
 
 constexpr int kThreads = 512;
 constexpr int kSide = 17;  // 2S+1
 constexpr int kBoundRows = 2;  // tile rows summed for the lower bound of the pruned search
+constexpr int kRefineParts = 4;  // lanes per block in the half-pixel refinement (1: 3.56, 2: 3.31, 4: 3.28 ms per 1 024 c5h pairs)
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
 {
@@ -104,10 +108,17 @@ __device__ __forceinline__ void wave_append(uint16_t *list, uint32_t *count, boo
     if (keep) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)item;
 }
 
-template <bool PRUNE>
+// REFINE (half-pixel refinement, origin S+1): the ring of every best match lies in the staged block row
+// once one more cur row above and below it is staged (rows -1 and 32), so the eight direction SADs are
+// summed out of LDS behind the search -- four lanes per block, four tile rows each, joined by shuffles --
+// instead of by a second pass over global memory (K2b, bound by the L1 rate of its per-lane row loads).
+template <bool PRUNE, bool REFINE>
 __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32_t total_wgs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int kLead = REFINE ? 1 : 0;            // cur rows staged above row 0 (and below row 31)
+    constexpr int kCurRows = 32 + 2 * kLead;
+    constexpr int kPadBytes = REFINE ? 16 : 0;       // the byte left of row -1 (ring column -1 of block 0) lives here
 
     const uint32_t logical = xcd_remap(blockIdx.x, total_wgs);
     const int W = a.w, nx = a.grid.nx, ny = a.grid.ny;
@@ -123,9 +134,9 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     int px = 0, py = 0;
     if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
     const int sh = px & 15;                                       // floor-mod
-    uint8_t *s_cur = smem;                           // frame rows [16*by + py, +32)
-    uint8_t *s_prev = smem + (size_t)32 * W;         // frame rows [16*by + 8, +16)
-    uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + (size_t)48 * W);
+    uint8_t *s_cur = smem + kPadBytes + (size_t)kLead * W;                // frame rows [16*by + py, +32) (REFINE: one more either side)
+    uint8_t *s_prev = smem + kPadBytes + (size_t)kCurRows * W;            // frame rows [16*by + 8, +16)
+    uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + kPadBytes + (size_t)(kCurRows + 16) * W);
     // Half-pixel refinement moves the grid origin to S+1 = 9: the same geometry on a frame whose
     // origin is moved by (1, 1) -- the flat copies start W+1 bytes later (byte-aligned loads);
     // the grid keeps every window inside the smaller frame.  K2b adds the directions.
@@ -146,7 +157,31 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         if (tid < 16 - sh)
             s_cur[(size_t)cur_chunks * 16 + tid] = (uint8_t)clamp_u8((int)g_cur[(size_t)cur_chunks * 16 + tid] + delta);
     }
-    if (org != 0 || sh != 0) {  // byte-aligned source: through registers
+    if constexpr (REFINE) {
+        // (origin 1: byte-aligned sources.)  Rows -1 .. 31 as one flat copy -- it ends 1 + sh bytes into
+        // frame row yc0 + 33, which exists --, row 32 only as far as the rings reach (the frame's last
+        // column: its flat copy would end past the frame's last row), and the one byte left of row -1.
+        const int flat_chunks = rows_ok ? 33 * (W / 16) : 0;
+        const int last_bytes = rows_ok ? W - 1 - sh : 0;
+        const int last_chunks = last_bytes / 16;
+        const uint8_t *g_flat = g_cur - W, *g_last = g_cur + (int64_t)32 * W;
+        uint8_t *s_flat = s_cur - W, *s_last = s_cur + (size_t)32 * W;
+        for (int c = tid; c < flat_chunks + last_chunks + prev_chunks; c += kThreads) {
+            const uint8_t *src;
+            uint8_t *dst;
+            bool is_cur = true;
+            if (c < flat_chunks) { src = g_flat + (size_t)c * 16; dst = s_flat + (size_t)c * 16; }
+            else if (c < flat_chunks + last_chunks) { src = g_last + (size_t)(c - flat_chunks) * 16; dst = s_last + (size_t)(c - flat_chunks) * 16; }
+            else { is_cur = false; src = g_prev + (size_t)(c - flat_chunks - last_chunks) * 16; dst = s_prev + (size_t)(c - flat_chunks - last_chunks) * 16; }
+            uint4 v;
+            __builtin_memcpy(&v, src, 16);
+            if (is_cur && delta != 0) v = sat_add_u8x16(v, delta);
+            *reinterpret_cast<uint4 *>(dst) = v;
+        }
+        const int odd = last_bytes - 16 * last_chunks;   // < 16 bytes of row 32, and the byte left of row -1
+        if (tid < odd) s_last[16 * last_chunks + tid] = (uint8_t)clamp_u8((int)g_last[16 * last_chunks + tid] + delta);
+        if (tid == 32 && rows_ok) s_flat[-1] = (uint8_t)clamp_u8((int)g_flat[-1] + delta);
+    } else if (org != 0 || sh != 0) {  // byte-aligned source: through registers
         for (int c = tid; c < cur_chunks + prev_chunks; c += kThreads) {
             const bool is_cur = c < cur_chunks;
             const int cc = is_cur ? c : c - cur_chunks;
@@ -309,25 +344,76 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         aof_block rec;
         rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
         const int xf = 16 * bx + px;
+        uint32_t refine_key = 0xFFFFFFFFu;   // REFINE: the best key of an accepted block
         if (rows_ok && xf >= 0 && xf + 32 <= Wb && diff >= (uint32_t)a.feature_threshold) {
             const uint32_t best = s_best[bx];
             const int idx = (int)(best & 0xFFFFu);
             rec.dx = (int8_t)(px + idx % kSide - 8);
             rec.dy = (int8_t)(py + idx / kSide - 8);
             rec.sad = (uint16_t)(best >> 16);
+            if (rec.sad != AOF_SAD_SKIPPED && (uint32_t)rec.sad < (uint32_t)a.value_threshold) refine_key = best;
         }
         a.blocks[pair * (int64_t)(nx * ny) + (int64_t)by * nx + bx] = rec;
+        if constexpr (REFINE) s_best[bx] = refine_key;   // (this lane alone reads and writes entry bx here)
+    }
+    if constexpr (REFINE) {
+        __syncthreads();
+        // Four lanes per block, lane `part` feeds tile rows 4 part .. 4 part + 3 with their window rows
+        // 4 part - 1 .. 4 part + 4 relative to the best match (aof_refine.hpp); the eight direction sums of
+        // the four slices add up across the quad (integer sums: any order).  Whole waves: shuffles.
+        uint8_t *subdirs = a.subdirs + pair * (int64_t)(nx * ny) + (int64_t)by * nx;
+        constexpr int kParts = kRefineParts, kRows = 16 / kParts;
+        for (int q = tid; q < (kParts * nx + 63) / 64 * 64; q += kThreads) {
+            const int bx = q / kParts, part = q % kParts;
+            const uint32_t key = bx < nx ? s_best[bx] : 0xFFFFFFFFu;
+            const bool live = key != 0xFFFFFFFFu;
+            RefineState<4, kRows> st;
+            st.init();
+            if (live) {
+                const int idx = (int)(key & 0xFFFFu), dxi = idx % kSide, dyi = idx / kSide;
+                uint32_t ref[kRows][4];
+#pragma unroll
+                for (int r = 0; r < kRows; r++) {
+                    const uint2 *p = reinterpret_cast<const uint2 *>(s_prev + (size_t)(kRows * part + r) * W + 16 * bx + 8);
+                    const uint2 lo = p[0], hi = p[1];
+                    ref[r][0] = lo.x; ref[r][1] = lo.y; ref[r][2] = hi.x; ref[r][3] = hi.y;
+                }
+                // ring row y of the slice: LDS row dyi + kRows part + y, bytes [xs + dxi - 1, + 18)
+                const int off0 = (dyi + kRows * part - 1) * W + (16 * bx + px - sh) + dxi - 1;
+                for_rows<-1, kRows>([&](auto yc) {
+                    constexpr int Y = decltype(yc)::value;
+                    const int off = off0 + (Y + 1) * W;
+                    const uint32_t *w = reinterpret_cast<const uint32_t *>(s_cur + (off & ~3));   // (off >= -W - 1: inside the pad)
+                    const uint32_t shb = (uint32_t)off & 3u;
+                    const uint32_t q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3], q4 = w[4], q5 = w[5];
+                    const uint32_t d[5] = {__builtin_amdgcn_alignbyte(q1, q0, shb), __builtin_amdgcn_alignbyte(q2, q1, shb),
+                                           __builtin_amdgcn_alignbyte(q3, q2, shb), __builtin_amdgcn_alignbyte(q4, q3, shb),
+                                           __builtin_amdgcn_alignbyte(q5, q4, shb)};
+                    st.template row<Y>(d, ref);
+                });
+            }
+#pragma unroll
+            for (int o = 1; o < kParts; o <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) st.acc[k] += (uint32_t)__shfl_xor((int)st.acc[k], o, 64);
+            }
+            if (bx < nx && part == 0) subdirs[bx] = (uint8_t)(live ? st.direction(key >> 16) : 8);
+        }
     }
 }
 
 size_t tile16_lds(const SearchArgs &a)
 {
     size_t bytes = (size_t)48 * a.w + 4 * (size_t)a.grid.nx + 16;
+    if (tile16_refines(a)) bytes += 2 * (size_t)a.w + 16 + 16;   // cur rows -1 and 32, the pad in front, dword reads past the last ring
     if (a.prune) bytes += 4 * (size_t)kSide * a.grid.nx + 16;   // lower bounds + item list + counter
     return bytes;
 }
 
 }  // namespace
+
+// Half-pixel refinement runs inside the search launch (k_search_tile16<.., true>) whenever directions are wanted.
+bool tile16_refines(const SearchArgs &a) { return a.subpixel && a.subdirs; }
 
 bool tile16_supported(const SearchArgs &a)
 {
@@ -346,7 +432,9 @@ int launch_search_tile16(const SearchArgs &a, void *stream)
     const int64_t total = a.n_pairs * a.grid.ny;
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     const size_t lds = tile16_lds(a);
-    void (*fn)(SearchArgs, uint32_t) = a.prune ? k_search_tile16<true> : k_search_tile16<false>;
+    void (*fn)(SearchArgs, uint32_t) =
+        tile16_refines(a) ? (a.prune ? k_search_tile16<true, true> : k_search_tile16<false, true>)
+                          : (a.prune ? k_search_tile16<true, false> : k_search_tile16<false, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
