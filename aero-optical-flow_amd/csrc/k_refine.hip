@@ -1,13 +1,12 @@
 // K2b -- half-pixel refinement as a separate pass (DESIGN.md "Spec": Half-pixel refinement).
 //
-// The 16x16 search kernel spreads a block over 17 lanes and keeps no ring of the best match,
-// so on configurations with half-pixel refinement it writes the integer records and this pass
-// adds the direction byte (the 8x8 kernels refine in place).  One lane per block, consecutive
+// Behind the searches that do not refine themselves: the generic wave-per-block kernel, and the
+// 16x16 kernel where its LDS tile with the two extra rows does not fit (k_search_tile16 refines
+// out of LDS otherwise, the 8x8 kernels in the search lane).  One lane per block, consecutive
 // lanes = consecutive (pair, block) items: the lane reads its reference tile and the (B+2)^2
-// neighbourhood of its best match straight from global memory (both frames were streamed by
-// the search a moment ago and sit in L2), rows as unaligned 8/16-byte loads, and feeds them to
-// the shared v_lerp_u8 arithmetic of aof_refine.hpp.  Blocks the search skipped or rejected get
-// direction 8 (none).
+// neighbourhood of its best match straight from global memory, rows as unaligned 8/16-byte
+// loads, and feeds them to the shared v_lerp_u8 arithmetic of aof_refine.hpp.  Blocks the
+// search skipped or rejected get direction 8 (none).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 #include "aof_refine.hpp"

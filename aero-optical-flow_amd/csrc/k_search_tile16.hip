@@ -12,6 +12,8 @@
 // The 17 dy-items of a block meet in an LDS atomicMin on the packed key
 // (sad << 16 | idx): integer min is order-independent and reproduces "first
 // minimum in scan order wins" exactly (16x16 max SAD 65 280 fits 16 bits, idx < 289).
+// Half-pixel configurations stage one more cur row either side and refine the accepted blocks
+// behind the search, out of the same tile (<.., REFINE>, below).
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 #include "aof_refine.hpp"
