@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Rewrites the headline paragraph of README.md (between the headline:begin / headline:end markers) from
+the evidence files profiles/<prefix>_bench_*.json and profiles/<round>_stream_latency.txt.
+    python tools/make_readme_headline.py r03_final"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
+rnd = prefix.split("_")[0]
+
+
+def load(name):
+    return json.loads(open(os.path.join(ROOT, "profiles", f"{prefix}_bench_{name}.json")).read().strip().splitlines()[-1])
+
+
+c2, c3, ing = load("c2"), load("c3"), load("ingest")
+l3, l1b, share, two = load("lanes_c3"), load("lanes_c1b"), load("share_p128"), load("share_p1024_two_batches")
+lat = [l for l in open(os.path.join(ROOT, "profiles", f"{rnd}_stream_latency.txt")) if "lane8" in l]
+
+
+def us(w, levels, resident):
+    for l in lat:
+        if l.startswith(f"{w}x{w} levels={levels} ") and f"resident={resident}" in l and " graph=1 " in l:
+            return float(re.search(r": ([\d.]+) us", l).group(1))
+    raise SystemExit("latency line missing")
+
+
+rf = c2["roofline"]
+txt = (f"Headline (`bench.py`, C2: 1 024 VGA pairs per launch, 8×8 SAD, ±4, exhaustive): **{c2['value']/1e6:.2f} M frame-pairs/s**, "
+       f"K2 {rf['kernel_ms']*1e3:.1f} µs per launch = **{rf['frac']*100:.1f} % of the 8 TB/s HBM roofline** (whole step {rf['frac_step']*100:.1f} %; "
+       f"box to box the kernel takes 204–213 µs, `profiles/{rnd}_box_spread.txt`; it is VALU-bound at ≈ 80 % of its SAD-issue floor, which caps "
+       f"the HBM fraction at 48 %), {two['value']/1e6:.2f} M with two batches in flight; "
+       f"C3 (two-level pyramid + equalisation) {c3['value']/1e6:.2f} M pairs/s, {l3['value']/1e6:.2f} M = **{l3['roofline']['frac_step']*100:.1f} %** "
+       f"(whole step) with two batches in flight; configs[3]'s per-GPU share of 128 pairs takes {share['ms_per_step']*1e3:.1f} µs per step against "
+       f"{two['ms_per_step']*1e3:.1f}–{c2['ms_per_step']*1e3:.1f} µs for all 1 024 pairs on one GPU "
+       f"(**{two['ms_per_step']/share['ms_per_step']:.1f}–{c2['ms_per_step']/share['ms_per_step']:.1f}×**; round 2: 5.1×); "
+       f"configs[0] in batch {l1b['value']/1e6:.0f} M pairs/s; frame ingest {ing['value']/1e6:.0f} M frames/s "
+       f"({ing['roofline']['frac']*100:.0f} % of the roofline, ≈ 92 % of what a plain copy of the same row pieces reaches); "
+       f"one `calcFlow()` call **{us(64, 1, 0):.2f} µs at 64×64 / {us(128, 2, 0):.2f} µs at 128×128 on two levels** through a replayed hipGraph "
+       f"whose tagged record the host polls for (round 2: 24.9 / 34.7 µs; the CPU oracle: 16 µs on one core), "
+       f"{us(64, 1, 1):.2f} / {us(128, 2, 1):.2f} µs served by the resident kernel (opt-in).")
+path = os.path.join(ROOT, "README.md")
+s = open(path).read()
+a = s.index("<!-- headline:begin -->") + len("<!-- headline:begin -->")
+b = s.index("<!-- headline:end -->")
+open(path, "w").write(s[:a] + "\n" + txt + "\n" + s[b:])
+print(txt)
