@@ -133,6 +133,49 @@ __device__ __forceinline__ void run_level(const SearchArgs &a, const FlowTail &t
     }
     __syncthreads();
 
+    // ---- D1 (half-pixel refinement): four lanes per accepted block, two tile rows each with their window
+    // rows -1 .. 2 relative to the best match (aof_refine.hpp); the eight direction sums of the four slices
+    // add up across the quad (integer sums: any order) and the direction rides back in bits 8..11 of the
+    // block's key (idx < 81 needs seven).  A quarter of the dependent row steps of one lane per block: this
+    // is the latency path.  Whole waves: shuffles.
+    if constexpr (SUBPIXEL) {
+        constexpr int kParts = 4, kRows = 8 / kParts;
+        for (int q = tid; q < (kParts * nb + 63) / 64 * 64; q += kThreads) {
+            const int blk = q / kParts, part = q % kParts;
+            const uint32_t key = blk < nb ? keys[blk] : 0xFFFFFFFFu;
+            const bool refine = key != 0xFFFFFFFFu && (key >> 16) < (uint32_t)a.value_threshold;
+            RefineState<2, kRows> st;
+            st.init();
+            if (refine) {
+                const int idx = (int)(key & 0xFFFFu);
+                const int by = blk / nx, bx = blk - by * nx;
+                const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y + kRows * part;
+                const int rx = i + m.px - 4 + idx % 9 - 1, ry = j + m.py - 4 + idx / 9 - 1;
+                uint32_t ref[kRows][2];
+#pragma unroll
+                for (int r = 0; r < kRows; r++) lds_bytes8(fp, (j + r) * W + i, ref[r]);
+                for_rows<-1, kRows>([&](auto yc) {
+                    constexpr int Y = decltype(yc)::value;
+                    uint32_t dd[3];
+                    lds_bytes12(fc, (ry + Y + 1) * W + rx, dd);
+                    if (m.delta != 0) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) dd[k] = sat_add_u8x4(dd[k], m.delta);
+                    }
+                    st.template row<Y>(dd, ref);
+                });
+            }
+#pragma unroll
+            for (int o = 1; o < kParts; o <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) st.acc[k] += (uint32_t)__shfl_xor((int)st.acc[k], o, 64);
+            }
+            // (the quad's four lanes read the key above, in the same wave, before this write)
+            if (refine && part == 0) keys[blk] = key | ((uint32_t)st.direction(key >> 16) << 8);
+        }
+        __syncthreads();
+    }
+
     // ---- D: one lane per block ----
     const bool live = tid < nb;   // nb <= kThreads
     aof_block rec;
@@ -142,32 +185,12 @@ __device__ __forceinline__ void run_level(const SearchArgs &a, const FlowTail &t
         const uint32_t key = keys[tid];
         const size_t item = (size_t)pair * (size_t)nb + (size_t)tid;
         if (key != 0xFFFFFFFFu) {
-            const int idx = (int)(key & 0xFFFFu);
+            const int idx = (int)(key & 0xFFu);
             rec.dx = (int8_t)(m.px + idx % 9 - 4);
             rec.dy = (int8_t)(m.py + idx / 9 - 4);
             rec.sad = (uint16_t)(key >> 16);
             if constexpr (SUBPIXEL) {
-                if ((uint32_t)rec.sad < (uint32_t)a.value_threshold) {
-                    const int by = tid / nx, bx = tid - by * nx;
-                    const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y;
-                    const int rx = i + m.px - 4 + idx % 9 - 1, ry = j + m.py - 4 + idx / 9 - 1;
-                    uint32_t ref[8][2];
-#pragma unroll
-                    for (int r = 0; r < 8; r++) lds_bytes8(fp, (j + r) * W + i, ref[r]);
-                    RefineState<2> st;
-                    st.init();
-                    for_rows<-1, 8>([&](auto yc) {
-                        constexpr int Y = decltype(yc)::value;
-                        uint32_t dd[3];
-                        lds_bytes12(fc, (ry + Y + 1) * W + rx, dd);
-                        if (m.delta != 0) {
-#pragma unroll
-                            for (int q = 0; q < 3; q++) dd[q] = sat_add_u8x4(dd[q], m.delta);
-                        }
-                        st.template row<Y>(dd, ref);
-                    });
-                    subdir = st.direction(rec.sad);
-                }
+                if ((uint32_t)rec.sad < (uint32_t)a.value_threshold) subdir = (int)((key >> 8) & 0xFu);
             }
         }
         reinterpret_cast<uint32_t *>(a.blocks)[item] = __builtin_bit_cast(uint32_t, rec);
