@@ -66,6 +66,19 @@ class WsLayout(C.Structure):
         "l0_blocks", "l0_subdirs", "l0_hist", "l1_hist")]
 
 
+class StreamStats(C.Structure):
+    """``aof_stream_stats`` (include/aof.h)."""
+    _fields_ = [("calls", C.c_uint64), ("resident_served", C.c_uint64), ("resident_launches", C.c_uint32),
+                ("resident_fallbacks", C.c_uint32), ("resident_lost", C.c_uint32), ("tagged_slow", C.c_uint32),
+                ("launch_call_us_max", C.c_float), ("start_latency_us_max", C.c_float),
+                ("last_report", C.c_char * 320)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["last_report"] = d["last_report"].decode(errors="replace")
+        return d
+
+
 class AofError(RuntimeError):
     def __init__(self, code, text):
         super().__init__(f"aof error {code}: {text}")
@@ -106,6 +119,8 @@ def _load():
         "aof_stream_reset": (C.c_int, [VP]),
         "aof_set_stream_graph": (C.c_int, [VP, C.c_int]),
         "aof_set_stream_resident": (C.c_int, [VP, C.c_int]),
+        "aof_stream_get_stats": (C.c_int, [VP, P(StreamStats)]),
+        "aof_set_vote_deadline_us": (C.c_int, [VP, C.c_uint32]),
         "aof_ingest_batch_device": (C.c_int, [P(IngestParams), VP, I64, I64, VP, I64, VP, VP]),
         "aof_derotate_batch_device": (C.c_int, [P(DerotateParams), VP, VP, I64, VP, VP]),
         "aof_exposure_msv": (C.c_float, [VP]),
@@ -265,7 +280,8 @@ class FlowEngine:
         self._check(lib.aof_set_split_coarse(self._ctx, int(on)))
 
     def set_reduce_fusion(self, on=True):
-        """8x8 tiles on large grids: reduce inside the search launch (default) or launch K3 separately."""
+        """8x8 tiles on large grids: on=True reduces inside the search launch (opt-in); the default
+        (on=False) launches K3 as a separate kernel behind the search."""
         if not hasattr(lib, "aof_set_reduce_fusion"):
             return   # (AOF_LIB pointing at an older build)
         self._check(lib.aof_set_reduce_fusion(self._ctx, int(on)))
@@ -398,6 +414,16 @@ class FlowEngine:
 
     def stream_resident_running(self) -> bool:
         return lib.aof_set_stream_resident(self._ctx, -1) == 1
+
+    def stream_stats(self) -> dict:
+        """Counters of the streaming entry point (``aof_stream_stats``)."""
+        st = StreamStats()
+        self._check(lib.aof_stream_get_stats(self._ctx, C.byref(st)))
+        return st.as_dict()
+
+    def set_vote_deadline_us(self, microseconds):
+        """Test knob: deadline of the finaliser waves of the in-launch reduction."""
+        self._check(lib.aof_set_vote_deadline_us(self._ctx, int(microseconds)))
 
     def stream_graph_active(self) -> bool:
         return lib.aof_set_stream_graph(self._ctx, -1) == 1

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "aof_internal.hpp"
 
@@ -42,6 +43,7 @@ struct aof_ctx {
     int cur_slot;          // slot holding the newest frame
     bool have_prev;
     bool host_ready;       // everything below exists (ensure_host_state)
+    bool host_dirty;       // part of it was abandoned to a lost resident kernel: rebuild before the next use
     aof_block *d_blocks;
     uint8_t *d_subdirs;
     aof_flow *d_flow;
@@ -62,11 +64,19 @@ struct aof_ctx {
     // resident form of the per-call path (aof_set_stream_resident): one workgroup stays on the device
     // and serves aof_stream_push_host through a mailbox in pinned memory
     bool resident_on;
-    bool resident_lost;         // a resident kernel did not leave when asked: what it reads is never freed
-    hipStream_t rstream;        // the resident kernel's own stream
+    bool resident_lost;         // a resident kernel did not leave when asked: nothing it may touch is ever freed
+    bool wedged;                // a bounded wait for the device ran out: every later call fails, destroy frees nothing
+    hipStream_t rstream;        // the resident kernel's own stream (highest priority: its own pool of hardware queues)
     ResidentBox *box;           // pinned, device-visible
     uint32_t rseq;              // number of the last request posted
+    uint32_t rlaunches;         // resident kernel instances started on `box`
     uint32_t rframe_req[2];     // request at which pinned frame b was posted as the newest frame, 0 = written otherwise
+    aof_stream_stats stats;     // aof_stream_get_stats
+    // device -> host fault word (pinned, its own allocation): a kernel that gave up on a device-side wait
+    // stores a non-zero code here; every entry point that enqueues work looks at it first
+    uint32_t *h_fault;
+    uint32_t vote_deadline_ticks;   // finaliser waves of the in-launch reduction give up after this (100 MHz ticks)
+    bool votes_captured;        // a captured graph holds an in-launch reduction: eager launches keep to K3
     // reduction inside the flat lane8 search (no K3 launch): the pairs' vote records, zero at rest
     uint32_t *d_votes;
     int64_t votes_pairs;        // records allocated
@@ -76,8 +86,13 @@ struct aof_ctx {
     bool votes_used;
 };
 
-constexpr int64_t kVotePairs = 8192;             // vote records per context (launches of more pairs keep K3)
+// Vote records per context (launches of more pairs keep K3).  2 048 finaliser waves are at most 256 per XCD --
+// half of an XCD's wave slots at the search kernel's occupancy -- so the search workgroups of ANOTHER
+// context's launch always find room beside them: two in-launch reductions in flight cannot wait for each
+// other (they could from 4 096 pairs on, until the deadline).
+constexpr int64_t kVotePairs = 2048;
 constexpr uint32_t kVoteStride = 128;            // words per record: 1 + 2 * 55 bins at the most (R = 13)
+constexpr uint32_t kVoteDeadlineTicks = 5000000; // 50 ms of the 100 MHz counter (aof_set_vote_deadline_us)
 
 namespace {
 
@@ -102,6 +117,65 @@ int fail(aof_ctx *ctx, int code, const char *fmt, ...)
         va_end(ap);
     }
     return code;
+}
+
+double seconds_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Waits until everything enqueued on `s` has completed, for at most `seconds`: hipStreamQuery never blocks,
+// hipStreamSynchronize has no time limit of its own.  hipErrorNotReady = the time ran out.
+hipError_t drain_bounded(hipStream_t s, double seconds)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        const double t = seconds_since(t0);
+        if (t > seconds) return hipErrorNotReady;
+        if (t > 200e-6) std::this_thread::sleep_for(std::chrono::microseconds(t > 5e-3 ? 500 : 20));
+    }
+}
+
+hipError_t event_wait_bounded(hipEvent_t ev, double seconds)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (seconds_since(t0) > seconds) return hipErrorNotReady;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+constexpr double kDrainS = 2.0;   // bounded waits for a stream of this library's kernels (each runs microseconds to milliseconds)
+
+// The device did not finish within a bounded wait, or reported a fault: the context stays unusable
+// (recovery = a new context) and aof_destroy frees nothing a kernel might still touch.
+int wedge(aof_ctx *ctx, const char *what, hipError_t e)
+{
+    ctx->wedged = true;
+    std::fprintf(stderr, "aof: %s: %s -- the context is disabled\n", what,
+                 e == hipErrorNotReady ? "the device did not finish within the time limit" : hipGetErrorString(e));
+    return fail(ctx, e == hipErrorNotReady ? -ETIMEDOUT : -EIO, "%s: %s", what,
+                e == hipErrorNotReady ? "the device did not finish within the time limit" : hipGetErrorString(e));
+}
+
+// Sticky device-side condition of the context, checked by every entry point that enqueues work: a bounded
+// wait that ran out earlier, or the fault word a kernel raised (a finaliser wave of the in-launch reduction
+// that gave up on its pair: that pair's record says quality 0, flags 0).  Like a sticky HIP error, it stays.
+int sticky_error(aof_ctx *ctx)
+{
+    if (ctx->wedged) return -EIO;   // (ctx->err still holds the text of the first report)
+    if (ctx->h_fault) {
+        const uint32_t code = __atomic_load_n(ctx->h_fault, __ATOMIC_ACQUIRE);
+        if (code)
+            return fail(ctx, -EIO, "a reduction inside a search launch gave up waiting for the votes of pair %u of its "
+                                   "launch (device-side deadline): that record carries quality 0 and no valid flag; "
+                                   "the context's vote memory is no longer trusted -- create a new context", code - 1);
+    }
+    return 0;
 }
 
 #define HIP_TRY(ctx, expr)                                                              \
@@ -180,7 +254,7 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
     case SK_LANE8: {
         // search + reduction in one launch when the context's vote memory can serve it; launches on
         // another stream than the last one wait for that one first (the records are shared)
-        const VoteMem vm = {ctx->d_votes, kVoteStride};
+        const VoteMem vm = {ctx->d_votes, kVoteStride, ctx->h_fault, ctx->vote_deadline_ticks};
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (ctx->separate_reduce || ctx->force_generic || !lane8_votes_supported(a, vm, ctx->votes_pairs) ||
             hipStreamIsCapturing(s, &cap) != hipSuccess) {
@@ -188,6 +262,13 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
             break;
         }
         const bool eager = cap == hipStreamCaptureStatusNone;
+        // A captured graph that holds an in-launch reduction is replayed whenever its owner likes and records
+        // no votes_done event: eager launches on this context keep to the separate K3 from then on, so that
+        // the library never puts a second user on the vote records behind the graph's back.
+        if (eager && ctx->votes_captured) {
+            rc = launch_search_lane8(a, s);
+            break;
+        }
         if (eager && ctx->votes_used && ctx->votes_stream != s &&
             hipStreamWaitEvent(s, ctx->votes_done, 0) != hipSuccess)
             return fail(ctx, -EIO, "cannot order the launch behind the context's previous one");
@@ -197,6 +278,7 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
             ctx->votes_stream = s;
             ctx->votes_used = true;
         }
+        if (!rc && !eager) ctx->votes_captured = true;   // (replays are the owner's to order: include/aof.h)
         *reduced = true;
         break;
     }
@@ -370,32 +452,48 @@ constexpr double kResidentHostTimeoutS = 0.25;      // the host gives up on a re
 
 // Asks the resident kernel to leave and waits for it (bounded by the kernel's own deadlines).  Must run
 // before anything that frees or reallocates what the kernel reads, and before a change of kernel choice.
-bool resident_stop(aof_ctx *ctx)   // false: it did not leave (never observed; its memory is then leaked, not freed)
+// The stop bit is only ever cleared after the DEVICE has cleared `running` (the kernel's last store): a
+// launched instance that has not started yet still finds the bit on its first poll and leaves at once.
+// false: it did not leave within a second (five lifetimes).  The box keeps its stop bit for good, the
+// context forgets the box, the stream and every buffer the kernel may still read or write (leaked, never
+// freed or reused), and aof_destroy frees no device memory at all (a hipFree waits for every kernel).
+bool resident_stop(aof_ctx *ctx)
 {
     if (!ctx->box || !ctx->rstream) return true;
-    bool left = true;
-    const unsigned long long word = __atomic_load_n(&ctx->box->word, __ATOMIC_ACQUIRE);
-    if (__atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE)) {
-        __atomic_store_n(&ctx->box->word, word | kResidentStopBit, __ATOMIC_RELEASE);
-        // The kernel clears `running` when it leaves -- at the latest on its 200 ms lifetime deadline.  Wait
-        // for THAT (bounded), and synchronise the stream only once it has happened: a stream
-        // synchronisation has no time limit of its own.
-        (void)hipStreamQuery(ctx->rstream);   // (makes sure the launch has been handed to the device)
-        const auto t0 = std::chrono::steady_clock::now();
-        while (__atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE) &&
-               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 1.0) {
-        }
-        if (__atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE)) {
-            std::fprintf(stderr, "aof: the resident kernel did not leave within 1 s of being asked to\n");
-            left = false;
-            ctx->resident_lost = true;
-        } else {
-            (void)hipStreamSynchronize(ctx->rstream);
+    ResidentBox *box = ctx->box;
+    if (!__atomic_load_n(&box->running, __ATOMIC_ACQUIRE)) return true;   // nothing launched since the last exit
+    const unsigned long long word = __atomic_load_n(&box->word, __ATOMIC_ACQUIRE);
+    __atomic_store_n(&box->word, word | kResidentStopBit, __ATOMIC_RELEASE);
+    // The kernel clears `running` when it leaves -- at the latest on its 200 ms lifetime deadline.  Wait for
+    // THAT, bounded.  No HIP call is needed for the launch to reach the device: hipLaunchKernelGGL has
+    // written the AQL packet and rung the queue's doorbell before it returned (direct dispatch; the
+    // launch-to-first-poll latency in aof_stream_stats is measured with the host spinning on pinned memory
+    // and nothing else).
+    const auto t0 = std::chrono::steady_clock::now();
+    while (__atomic_load_n(&box->running, __ATOMIC_ACQUIRE) && seconds_since(t0) < 1.0) {
+    }
+    hipError_t e = hipSuccess;
+    if (!__atomic_load_n(&box->running, __ATOMIC_ACQUIRE)) {
+        // it has left; the stream retires the launch within microseconds -- bounded all the same
+        e = drain_bounded(ctx->rstream, kDrainS);
+        if (e == hipSuccess) {
+            __atomic_store_n(&box->word, word & ~kResidentStopBit, __ATOMIC_RELEASE);
+            return true;
         }
     }
-    __atomic_store_n(&ctx->box->word, word & ~kResidentStopBit, __ATOMIC_RELEASE);
-    __atomic_store_n(&ctx->box->running, 0u, __ATOMIC_RELEASE);
-    return left;
+    std::fprintf(stderr, "aof: the resident kernel did not leave within 1 s of being asked to (launch %u, started %u, "
+                         "served %u, exited at %u, on device %u, stream: %s): its buffers are abandoned\n",
+                 ctx->rlaunches, (unsigned)box->started, (unsigned)box->done, (unsigned)box->exited, (unsigned)box->running,
+                 e == hipSuccess ? hipGetErrorString(hipStreamQuery(ctx->rstream)) : hipGetErrorString(e));
+    ctx->resident_lost = true;
+    ctx->stats.resident_lost++;
+    ctx->resident_on = false;
+    // forget (leak) everything the kernel may still touch; the host-buffer state is rebuilt on the next call
+    ctx->box = nullptr; ctx->rstream = nullptr;
+    ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr; ctx->h_tag = nullptr;
+    ctx->d_blocks = nullptr; ctx->d_subdirs = nullptr; ctx->d_flow = nullptr; ctx->d_ws = nullptr;
+    ctx->host_dirty = true;
+    return false;
 }
 
 }  // namespace
@@ -428,12 +526,15 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
         const size_t bytes = (size_t)kVotePairs * kVoteStride * sizeof(uint32_t);
         if (hipMalloc((void **)&ctx->d_votes, bytes) != hipSuccess || hipMemset(ctx->d_votes, 0, bytes) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->votes_done, hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc((void **)&ctx->h_fault, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess) {
             aof_destroy(ctx);
             return -EIO;
         }
+        *ctx->h_fault = 0;
         ctx->votes_pairs = kVotePairs;
     }
+    ctx->vote_deadline_ticks = kVoteDeadlineTicks;
     ctx->separate_reduce = true;   // the in-launch reduction is opt-in (aof_set_reduce_fusion)
 
     *out = ctx;
@@ -445,21 +546,32 @@ void aof_destroy(aof_ctx *ctx)
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
     (void)resident_stop(ctx);   // before anything it reads is freed
-    if (ctx->resident_lost) {   // (leak the pinned buffers and the stream rather than free them under a live kernel)
-        ctx->box = nullptr; ctx->rstream = nullptr;
-        ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr; ctx->h_tag = nullptr;
-        ctx->d_blocks = nullptr; ctx->d_subdirs = nullptr; ctx->d_flow = nullptr; ctx->d_ws = nullptr;
-    }
-    if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
-    if (ctx->box) (void)hipHostFree(ctx->box);
+    // Every wait here is bounded: a hipFree / hipStreamDestroy / hipStreamSynchronize waits for the device
+    // without a time limit, so they only run once the context's own work is known to have drained.  If it
+    // has not (a lost resident kernel, a wedged device, a fault), the context's device and pinned memory and
+    // its streams are leaked -- the caller (calcFlow's owner holds _mainloop_lock, mainloop.cpp:283) gets
+    // control back either way.
+    bool leak = ctx->resident_lost || ctx->wedged;
+    hipError_t e = hipSuccess;
+    if (!leak && ctx->stream && (e = drain_bounded(ctx->stream, kDrainS)) != hipSuccess) leak = true;
+    if (!leak && ctx->votes_done && ctx->votes_used && (e = event_wait_bounded(ctx->votes_done, kDrainS)) != hipSuccess)
+        leak = true;
     if (ctx->ev) {
         for (int k = 0; k < AOF_K_COUNT; k++)
             for (int r = 0; r < AOF_PROFILE_RING; r++)
-                for (int e = 0; e < 2; e++)
-                    if (ctx->ev[k][r][e]) (void)hipEventDestroy(ctx->ev[k][r][e]);
+                for (int ev = 0; ev < 2; ev++)
+                    if (ctx->ev[k][r][ev]) (void)hipEventDestroy(ctx->ev[k][r][ev]);
         delete[] ctx->ev;
     }
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (leak) {
+        std::fprintf(stderr, "aof: destroying a context whose device work has not drained (%s): its device memory, pinned "
+                             "memory and streams are leaked, not freed\n",
+                     ctx->resident_lost ? "resident kernel lost" : ctx->wedged ? ctx->err : hipGetErrorString(e));
+        delete ctx;
+        return;
+    }
+    if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
+    if (ctx->box) (void)hipHostFree(ctx->box);
     for (int i = 0; i < 2; i++) if (ctx->push_graph[i]) (void)hipGraphExecDestroy(ctx->push_graph[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->h_frame) (void)hipHostFree(ctx->h_frame);
@@ -471,8 +583,9 @@ void aof_destroy(aof_ctx *ctx)
     if (ctx->d_subdirs) (void)hipFree(ctx->d_subdirs);
     if (ctx->d_flow) (void)hipFree(ctx->d_flow);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
-    if (ctx->votes_done) { (void)hipEventSynchronize(ctx->votes_done); (void)hipEventDestroy(ctx->votes_done); }
+    if (ctx->votes_done) (void)hipEventDestroy(ctx->votes_done);
     if (ctx->d_votes) (void)hipFree(ctx->d_votes);
+    if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     delete ctx;
 }
 
@@ -505,9 +618,12 @@ static void drop_push_graphs(aof_ctx *ctx)
 {
     if (!ctx->push_graph[0] && !ctx->push_graph[1]) return;
     DeviceGuard guard(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 2; i++)
-        if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
+    if (ctx->stream && !ctx->wedged) {
+        const hipError_t e = drain_bounded(ctx->stream, kDrainS);
+        if (e != hipSuccess) (void)wedge(ctx, "draining the per-call stream before its graphs are dropped", e);
+    }
+    for (int i = 0; i < 2; i++)   // (a wedged context leaks the executables: a replay may still be running)
+        if (ctx->push_graph[i]) { if (!ctx->wedged) (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
 }
 
 int aof_set_force_generic(aof_ctx *ctx, int on)
@@ -592,6 +708,7 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
     if (!ctx) return -EINVAL;
     if (n_pairs < 0 || (n_pairs > 0 && (!d_prev || !d_cur || !d_flows)))
         return fail(ctx, -EINVAL, "null frame or flow pointer");
+    if (int sticky = sticky_error(ctx)) return sticky;
     if (n_pairs == 0) return 0;
     const aof_params &p = ctx->params;
     if (pair_stride < (int64_t)p.width * p.height && n_pairs > 1)
@@ -672,14 +789,31 @@ int aof_derotate_batch_device(const aof_derotate_params *p, const aof_flow *d_fl
 
 // ---- host-buffer conveniences ------------------------------------------------
 
+// Forgets the host-buffer state without freeing it (part of it belongs to a resident kernel that did not
+// leave, or the device did not drain: a hipFree would wait for that without a time limit).
+static void forget_host_state(aof_ctx *ctx)
+{
+    ctx->stream = nullptr; ctx->h_frame = nullptr;
+    ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr; ctx->h_tag = nullptr;
+    ctx->d_frames[0] = ctx->d_frames[1] = nullptr; ctx->d_pair[0] = ctx->d_pair[1] = nullptr;
+    ctx->d_blocks = nullptr; ctx->d_subdirs = nullptr; ctx->d_flow = nullptr; ctx->d_ws = nullptr;
+    ctx->push_graph[0] = ctx->push_graph[1] = nullptr;
+    ctx->host_ready = false;
+    ctx->host_dirty = false;
+    ctx->have_prev = false;
+}
+
 static void free_host_state(aof_ctx *ctx)
 {
     (void)resident_stop(ctx);
-    if (ctx->resident_lost) {
-        ctx->h_frames[0] = ctx->h_frames[1] = nullptr; ctx->h_flow = nullptr; ctx->h_tag = nullptr;
-        ctx->d_blocks = nullptr; ctx->d_subdirs = nullptr; ctx->d_flow = nullptr; ctx->d_ws = nullptr;
+    if (ctx->resident_lost || ctx->wedged || ctx->host_dirty) { forget_host_state(ctx); return; }
+    if (ctx->stream) {
+        const hipError_t e = drain_bounded(ctx->stream, kDrainS);
+        if (e != hipSuccess) { (void)wedge(ctx, "draining the per-call stream", e); forget_host_state(ctx); return; }
+        for (int i = 0; i < 2; i++)
+            if (ctx->push_graph[i]) { (void)hipGraphExecDestroy(ctx->push_graph[i]); ctx->push_graph[i] = nullptr; }
+        (void)hipStreamDestroy(ctx->stream); ctx->stream = nullptr;
     }
-    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); ctx->stream = nullptr; }
     if (ctx->h_frame) { (void)hipHostFree(ctx->h_frame); ctx->h_frame = nullptr; }
     for (int i = 0; i < 2; i++) if (ctx->h_frames[i]) { (void)hipHostFree(ctx->h_frames[i]); ctx->h_frames[i] = nullptr; }
     if (ctx->h_flow) { (void)hipHostFree(ctx->h_flow); ctx->h_flow = nullptr; ctx->h_tag = nullptr; }
@@ -726,6 +860,7 @@ static int alloc_host_state(aof_ctx *ctx)
 // overwriting (leaking) live handles.
 static int ensure_host_state(aof_ctx *ctx)
 {
+    if (ctx->host_dirty) forget_host_state(ctx);   // (abandoned to a lost resident kernel: start over with fresh buffers)
     if (ctx->host_ready) return 0;
     const int rc = alloc_host_state(ctx);
     if (rc) {
@@ -814,6 +949,7 @@ int aof_flow_pair_host(aof_ctx *ctx, const uint8_t *prev, const uint8_t *cur, ao
 {
     if (!ctx) return -EINVAL;
     if (!prev || !cur || !flow) return fail(ctx, -EINVAL, "null frame or flow pointer");
+    if (int sticky = sticky_error(ctx)) return sticky;
     DeviceGuard guard(ctx->device);
     int rc = ensure_host_state(ctx);
     if (rc) return rc;
@@ -831,15 +967,25 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
 {
     if (!ctx) return -EINVAL;
     if (!frame || !flow) return fail(ctx, -EINVAL, "null frame or flow pointer");
+    if (int sticky = sticky_error(ctx)) return sticky;
     DeviceGuard guard(ctx->device);
     int rc = ensure_host_state(ctx);
     if (rc) return rc;
     const size_t bytes = (size_t)ctx->params.width * ctx->params.height;
-    const int slot = ctx->have_prev ? 1 - ctx->cur_slot : 0;
+    int slot = ctx->have_prev ? 1 - ctx->cur_slot : 0;
+    if (ctx->have_prev) ctx->stats.calls++;
     if (ctx->have_prev && ctx->resident_on && ctx->zero_copy && !ctx->profiling) {
         bool served = false;
         rc = stream_push_resident(ctx, frame, flow, slot, &served);
         if (served || rc) return rc;   // (not served and no error: this configuration takes the paths below)
+        if (ctx->host_dirty) {
+            // The kernel neither answered nor left: the pinned frames it may still read are abandoned, the
+            // older frame with them.  This frame starts a new sequence on fresh buffers (return 1, as after
+            // aof_stream_reset) -- one flow sample is lost, nothing wrong is ever reported.
+            rc = ensure_host_state(ctx);
+            if (rc) return rc;
+            slot = 0;
+        }
     }
     if (ctx->have_prev && !ctx->graph_disabled && !ctx->profiling) {
         if (!ctx->push_graph[slot]) build_push_graph(ctx, slot);
@@ -865,6 +1011,32 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
     return 0;
 }
 
+// The tagged 16-byte record of the per-call paths (k_flow_small_tagged, k_flow_resident): the device
+// publishes it with ONE 16-byte store to a 16-byte aligned address in pinned, coherent host memory -- one
+// PCIe write, which the root complex commits to its cache line as a whole -- and the top byte of `count`
+// (word 2) carries the tag.  The host reads it with ONE 16-byte load (an aligned SSE load is a single
+// access), checks the tag IN THAT COPY, and reads once more to see the same bytes again.
+typedef uint32_t RecordWords __attribute__((vector_size(16)));
+static inline bool read_tagged_record(const aof_flow *pinned, uint32_t tag, aof_flow *out)
+{
+    const volatile RecordWords *rec = reinterpret_cast<const volatile RecordWords *>(pinned);
+    const RecordWords a = *rec;
+    if ((a[2] & 0xFF000000u) != tag) return false;
+    const RecordWords b = *rec;
+    if (a[0] != b[0] || a[1] != b[1] || a[2] != b[2] || a[3] != b[3]) return false;
+    std::memcpy(out, &a, sizeof(*out));
+    out->count &= 0x00FFFFFFu;
+    return true;
+}
+
+// Before a request is posted: whatever record is in place (first use, a record of the other path) must not
+// carry the new request's tag.
+static inline void retag_stale_record(aof_flow *pinned, uint32_t tag)
+{
+    volatile uint32_t *word = &reinterpret_cast<volatile uint32_t *>(pinned)[2];
+    if ((*word & 0xFF000000u) == tag) *word ^= 0x80000000u;
+}
+
 // Same contract as the plain path above, one hipGraphLaunch per frame.
 static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow, int slot)
 {
@@ -872,58 +1044,69 @@ static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow,
     std::memcpy(ctx->zero_copy ? ctx->h_frames[slot] : ctx->h_frame, frame,
                 (size_t)ctx->params.width * ctx->params.height);
     const bool tagged = ctx->push_tagged[slot];
-    volatile uint32_t *word = &reinterpret_cast<volatile uint32_t *>(ctx->h_flow)[2];
     uint32_t tag = 0;
     if (tagged) {
         tag = ++ctx->rseq << 24;
-        if ((*word & 0xFF000000u) == tag) *word ^= 0x80000000u;   // (first use, or a record of another path: make its tag differ)
+        retag_stale_record(ctx->h_flow, tag);
         __atomic_store_n(ctx->h_tag, ctx->rseq, __ATOMIC_RELEASE);
     }
     hipError_t e = hipGraphLaunch(ctx->push_graph[slot], ctx->stream);
     if (e == hipSuccess && tagged) {
-        // The record arrives as ONE 16-byte store with the tag in the top byte of `count`: the kernel is
-        // through with both frames when it is there, and the runtime's own completion path (longer than
-        // the kernel) is not waited for.  A record that stays away is left to the stream: it drains or
-        // reports the fault.
+        // The record arrives tagged: the kernel is through with both frames when it is there, and the
+        // runtime's own completion path (longer than the kernel) is not waited for.  A record that stays
+        // away for 2 ms is left to the stream -- bounded: the stream drains (and the record is there), or it
+        // reports the fault, or the time runs out and the context is disabled.
         const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 1; (*word & 0xFF000000u) != tag; spins++) {
-            if ((spins & 0x3FFu) == 0 &&
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kTaggedRecordWaitS) {
-                e = hipStreamSynchronize(ctx->stream);
-                if (e == hipSuccess && (*word & 0xFF000000u) != tag) e = hipErrorUnknown;
+        for (unsigned spins = 1; !read_tagged_record(ctx->h_flow, tag, flow); spins++) {
+            if ((spins & 0x3FFu) == 0 && seconds_since(t0) > kTaggedRecordWaitS) {
+                ctx->stats.tagged_slow++;
+                e = drain_bounded(ctx->stream, kDrainS);
+                if (e == hipSuccess && !read_tagged_record(ctx->h_flow, tag, flow)) e = hipErrorUnknown;
                 break;
             }
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
     } else if (e == hipSuccess) {
         e = hipStreamSynchronize(ctx->stream);
+        *flow = *ctx->h_flow;
     }
     if (e != hipSuccess) {
         ctx->have_prev = false;
+        if (e == hipErrorNotReady) return wedge(ctx, "per-call graph replay", e);
         return fail(ctx, -EIO, "graph replay: %s", hipGetErrorString(e));
     }
-    *flow = *ctx->h_flow;
-    if (tagged) flow->count &= 0x00FFFFFFu;
     ctx->cur_slot = slot;
     return 0;
 }
 
-// The resident path: post the request, make sure the kernel is there, wait for its completion word.
-// *served = false (and 0) when the one-workgroup kernel does not serve this configuration.
+// The resident path: post the request, make sure the kernel is there, wait for its tagged record.
+// *served = false (and 0) when the one-workgroup kernel does not serve this configuration, or when it did
+// not answer (the caller's frame then takes the launch-per-call path).
 static int stream_push_resident(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow, int slot, bool *served)
 {
     const aof_params &p = ctx->params;
     const size_t bytes = (size_t)p.width * p.height;
     *served = false;
     if (!ctx->box) {
+        // The kernel's own stream at the HIGHEST priority: the runtime keeps a separate pool of hardware
+        // queues per priority, so this stream never shares a hardware queue with the context's other stream,
+        // the caller's or torch's (all normal priority) -- on a shared queue every packet carries the barrier
+        // bit, and a parked resident kernel would hold up the other stream's work for up to its lifetime
+        // (and be held up by it).  It can only meet other contexts' resident streams there, from the fifth on
+        // (GPU_MAX_HW_QUEUES = 4): a resident kernel queued behind another one starts when that one leaves,
+        // at most 200 ms later, which is inside the 250 ms a request waits.
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipHostMalloc((void **)&ctx->box, sizeof(ResidentBox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-            hipStreamCreateWithFlags(&ctx->rstream, hipStreamNonBlocking) != hipSuccess) {
+            (hipStreamCreateWithPriority(&ctx->rstream, hipStreamNonBlocking, greatest) != hipSuccess &&
+             hipStreamCreateWithFlags(&ctx->rstream, hipStreamNonBlocking) != hipSuccess)) {
             if (ctx->box) { (void)hipHostFree(ctx->box); ctx->box = nullptr; }
+            ctx->rstream = nullptr;
             ctx->resident_on = false;
             (void)hipGetLastError();
             return 0;
         }
         std::memset(ctx->box, 0, sizeof(ResidentBox));
+        ctx->rlaunches = 0;
     }
     aof_ws_layout L;
     aof_workspace_layout(&p, 1, &L);
@@ -937,46 +1120,69 @@ static int stream_push_resident(aof_ctx *ctx, const uint8_t *frame, aof_flow *fl
     std::memcpy(ctx->h_frames[slot], frame, bytes);
     uint32_t seq = ++ctx->rseq;
     if (seq == 0) seq = ++ctx->rseq;   // 0 means "no request" to the kernel
-    volatile uint32_t *tagged = &reinterpret_cast<volatile uint32_t *>(ctx->h_flow)[2];
     const uint32_t tag = seq << 24;
-    if ((*tagged & 0xFF000000u) == tag) *tagged ^= 0x80000000u;   // (first use, or a record of another path: make its tag differ)
+    retag_stale_record(ctx->h_flow, tag);
     __atomic_store_n(&box->word, resident_word(seq, slot, ctx->rframe_req[1 - slot]), __ATOMIC_RELEASE);   // the frame bytes first
     ctx->rframe_req[slot] = seq;
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    // The record arrives as ONE 16-byte store whose top `count` byte carries the request's low byte: poll
-    // for that tag (the record in place is the previous request's, whose tag differs).
-    for (;;) {
-        if ((*tagged & 0xFF000000u) == tag) break;
+    // The clock of the request: restarted whenever a launch returns -- the FIRST launch of the kernel in a
+    // process loads its code object and creates the stream's hardware queue inside hipLaunchKernelGGL, which
+    // takes longer than any answer (measured: aof_stream_stats.launch_call_us_max), and that is not the
+    // kernel failing to answer.
+    auto t0 = std::chrono::steady_clock::now();
+    bool launched = false, start_seen = true;
+    for (unsigned spins = 0;;) {
+        if (read_tagged_record(ctx->h_flow, tag, flow)) break;
         if (!__atomic_load_n(&box->running, __ATOMIC_ACQUIRE)) {
             // not there (first call, or it left on its idle / lifetime deadline): start it behind its
             // predecessor, serving from the last request that one completed
-            if ((*tagged & 0xFF000000u) == tag) break;
+            if (read_tagged_record(ctx->h_flow, tag, flow)) break;
             __atomic_store_n(&box->running, 1u, __ATOMIC_RELEASE);
+            const auto l0 = std::chrono::steady_clock::now();
             const int lrc = launch_flow_resident(sm, box, ctx->h_flow, ctx->h_frames[0], ctx->h_frames[1],
-                                                 __atomic_load_n(&box->done, __ATOMIC_ACQUIRE), kResidentIdleTicks,
-                                                 kResidentLifeTicks, ctx->rstream);
+                                                 __atomic_load_n(&box->done, __ATOMIC_ACQUIRE), ++ctx->rlaunches,
+                                                 kResidentIdleTicks, kResidentLifeTicks, ctx->rstream);
             if (lrc) {
+                // nothing was enqueued: the flag is the host's to take back
                 __atomic_store_n(&box->running, 0u, __ATOMIC_RELEASE);
                 ctx->resident_on = false;
                 ctx->have_prev = false;
                 return fail(ctx, -EIO, "resident kernel launch: %s", hipGetErrorString((hipError_t)lrc));
             }
+            t0 = std::chrono::steady_clock::now();
+            const float us = (float)(std::chrono::duration<double>(t0 - l0).count() * 1e6);
+            if (us > ctx->stats.launch_call_us_max) ctx->stats.launch_call_us_max = us;
+            ctx->stats.resident_launches++;
+            launched = true;
+            start_seen = false;
+            continue;
         }
-        if ((++spins & 0x3FFu) == 0 &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kResidentHostTimeoutS) {
+        if (!start_seen && __atomic_load_n(&box->started, __ATOMIC_ACQUIRE) == ctx->rlaunches) {
+            // launch return -> the kernel's first instruction on the device, with no HIP call in between
+            const float us = (float)(seconds_since(t0) * 1e6);
+            if (us > ctx->stats.start_latency_us_max) ctx->stats.start_latency_us_max = us;
+            start_seen = true;
+        }
+        if ((++spins & 0x3FFu) == 0 && seconds_since(t0) > kResidentHostTimeoutS) {
             // no answer: stop it, leave the resident mode and let the caller's frame take the graph path
-            std::fprintf(stderr, "aof: the resident kernel did not answer request %u within %.0f ms (record word %08x, served %u, "
-                                 "on device %u): falling back to one launch per call\n", seq, kResidentHostTimeoutS * 1e3,
-                         (unsigned)*tagged, (unsigned)box->done, (unsigned)box->running);
-            (void)resident_stop(ctx);
+            const hipError_t q = hipStreamQuery(ctx->rstream);
+            std::snprintf(ctx->stats.last_report, sizeof(ctx->stats.last_report),
+                          "request %u unanswered for %.0f ms%s: record word %08x, launch %u, started %u, served %u, "
+                          "exited at %u, on device %u, stream %s, longest launch call %.0f us",
+                          seq, seconds_since(t0) * 1e3, launched ? " after this call's launch returned" : "",
+                          (unsigned)reinterpret_cast<volatile uint32_t *>(ctx->h_flow)[2], ctx->rlaunches,
+                          (unsigned)box->started, (unsigned)box->done, (unsigned)box->exited, (unsigned)box->running,
+                          q == hipSuccess ? "drained" : q == hipErrorNotReady ? "busy" : hipGetErrorString(q),
+                          ctx->stats.launch_call_us_max);
+            std::fprintf(stderr, "aof: the resident kernel did not answer (%s): falling back to one launch per call\n",
+                         ctx->stats.last_report);
+            ctx->stats.resident_fallbacks++;
+            (void)resident_stop(ctx);   // (if it does not leave either, its buffers are abandoned: host_dirty)
             ctx->resident_on = false;
+            (void)hipGetLastError();
             return 0;
         }
     }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    *flow = *ctx->h_flow;
-    flow->count &= 0x00FFFFFFu;
+    ctx->stats.resident_served++;
     ctx->cur_slot = slot;
     *served = true;
     return 0;
@@ -988,6 +1194,20 @@ int aof_set_stream_resident(aof_ctx *ctx, int on)
     if (on < 0) return (ctx->box && __atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE)) ? 1 : 0;
     if (!on) { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }
     ctx->resident_on = on != 0;
+    return 0;
+}
+
+int aof_stream_get_stats(const aof_ctx *ctx, aof_stream_stats *out)
+{
+    if (!ctx || !out) return -EINVAL;
+    *out = ctx->stats;
+    return 0;
+}
+
+int aof_set_vote_deadline_us(aof_ctx *ctx, uint32_t microseconds)
+{
+    if (!ctx) return -EINVAL;
+    ctx->vote_deadline_ticks = microseconds > 10000000u ? 1000000000u : microseconds * 100u;   // 100 MHz counter
     return 0;
 }
 

@@ -60,6 +60,8 @@ struct FlowTail {
 struct VoteMem {
     uint32_t *base;     // [pairs][stride] words
     uint32_t stride;    // words per pair, a multiple of 64 (256 bytes: pairs never share a line)
+    uint32_t *fault;    // pinned host word of the context: a finaliser that gives up stores pair + 1 here
+    uint32_t deadline_ticks;   // finaliser waves give up after this many ticks of the 100 MHz counter
 };
 
 // Everything one search launch needs; passed to the kernels by value.
@@ -177,10 +179,13 @@ struct ResidentBox {
     unsigned long long word;
     uint32_t pad0[14];
     uint32_t done;      // device: number of the last request served (its record is in place)
-    uint32_t running;   // host sets 1 before the launch, the device 0 when it leaves
+    uint32_t running;   // host sets 1 before the launch, the device 0 when it leaves (the host never clears it)
     uint32_t exited;    // device: `done` at the moment it left
-    uint32_t pad1[13];
+    uint32_t started;   // device: launch number of the instance that last reached its polling loop (diagnostics:
+                        // tells "never got onto the device" from "on the device but not answering")
+    uint32_t pad1[12];
 };
+static_assert(sizeof(ResidentBox) == 128, "two cache lines: host -> device, device -> host");
 constexpr unsigned long long kResidentStopBit = 1ull << 63;
 inline unsigned long long resident_word(uint32_t request, int slot, uint32_t prev_request)
 {
@@ -189,7 +194,8 @@ inline unsigned long long resident_word(uint32_t request, int slot, uint32_t pre
 }
 // host_record: the pinned 16-byte record the host polls (top byte of `count` = low byte of the request).
 int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_record, const uint8_t *frame_a,
-                         const uint8_t *frame_b, uint32_t served, uint64_t idle_ticks, uint64_t life_ticks, void *stream);
+                         const uint8_t *frame_b, uint32_t served, uint32_t launch_no, uint64_t idle_ticks,
+                         uint64_t life_ticks, void *stream);
 int launch_reduce(const ReduceArgs &a, void *stream);
 int launch_derotate(const aof_derotate_params &p, const aof_flow *flows, const aof_gyro *gyro,
                     int64_t n, float *out, void *stream);

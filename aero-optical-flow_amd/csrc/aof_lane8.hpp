@@ -185,7 +185,14 @@ __device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint3
 // are then not read.
 struct PairMeta { int px, py, delta; };
 
-template <bool SUBPIXEL, bool PRUNE, bool EQ = true>
+// PACKED: the predictor rides through the SAD stream as two bytes of ONE register.  The kernels that keep
+// their lanes for the votes sit exactly at the 128 VGPRs of four waves per SIMD; without it two of their
+// instantiations (no half-pixel step, equalising) spill one accumulator into scratch in the middle of the
+// stream.  Only those two use it: the code hipcc emits for a kernel here depends on WHICH other kernels of
+// the translation unit inline the same instantiation of this function (measured round 4: taking the flat
+// vote kernel off search_block<false, false, false> changes the record epilogue of the plain C2 kernel,
+// which shares it, and costs that kernel 2.5 %), so the headline kernel's instantiation keeps its callers.
+template <bool SUBPIXEL, bool PRUNE, bool EQ = true, bool PACKED = false>
 __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, uint32_t blk, uint32_t item0, bool live,
                                             aof_block &rec, int &start_row, int &prune_pays,
                                             const PairMeta *given = nullptr)
@@ -292,6 +299,10 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
 #pragma unroll
         for (int s = 0; s < 16; s++) win[s] = sat_add_u8x16(win[s], delta);
     }
+    if constexpr (PACKED) {
+        px = (int)(((uint32_t)px & 0xFFu) | (((uint32_t)py & 0xFFu) << 8));
+        asm volatile("" : "+v"(px));   // (opaque: one register from here to the end of the SAD stream)
+    }
     uint32_t best = 0xFFFFFFFFu;
     if constexpr (PRUNE) {
         const unsigned long long needing = __ballot(need);
@@ -321,6 +332,10 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
         best = exhaustive_search<EQ>(win, ref, delta);
     }
     const int idx = (int)(best & 0xFFFFu);
+    if constexpr (PACKED) {
+        py = (int8_t)((uint32_t)px >> 8);
+        px = (int8_t)((uint32_t)px & 0xFFu);
+    }
     rec.dx = (int8_t)(px + idx % 9 - 4);
     rec.dy = (int8_t)(py + idx / 9 - 4);
     rec.sad = (uint16_t)(best >> 16);

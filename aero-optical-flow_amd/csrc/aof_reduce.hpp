@@ -257,12 +257,15 @@ __device__ __forceinline__ void vote_and_arrive(const VoteMem &vm, int range, ui
                                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Finaliser side: ONE WAVE per pair (all 64 lanes), n <= 62.  Gives up after `deadline_ticks` of the
+// Finaliser side: ONE WAVE per pair (all 64 lanes), n <= 62.  Gives up after vm.deadline_ticks of the
 // 100 MHz real-time counter (a search wave that never arrives means the launch is broken anyway): the
-// record is zeroed all the same and the flow record is written as all ones, which no valid result is.
-__device__ __forceinline__ void await_votes_and_finalise(const VoteMem &vm, const FlowTail &tail, uint32_t pair,
-                                                         uint64_t deadline_ticks)
+// pair's flow record then says "nothing measured" -- flow 0, count 0, quality 0, NO valid flag -- and the
+// wave raises the context's fault word in pinned host memory (pair + 1), which makes every later call on the
+// context fail (sticky_error in aof_capi.hip): voters that come late add into a record this wave has
+// already zeroed, so the context's vote memory cannot be trusted again.
+__device__ __forceinline__ void await_votes_and_finalise(const VoteMem &vm, const FlowTail &tail, uint32_t pair)
 {
+    const uint64_t deadline_ticks = vm.deadline_ticks;
     const int centre = 2 * tail.range + 1, n = 2 * centre + 1, lane = (int)(threadIdx.x & 63);
     uint32_t *rec = vm.base + (size_t)pair * vm.stride, *hist_x = rec + 2, *hist_y = rec + 2 + n;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
@@ -295,9 +298,10 @@ __device__ __forceinline__ void await_votes_and_finalise(const VoteMem &vm, cons
     }
     if (!complete) {
         if (lane == 0) {
-            aof_flow bad;
-            __builtin_memset(&bad, 0xFF, sizeof(bad));
-            tail.flows[pair] = bad;
+            aof_flow none;
+            __builtin_memset(&none, 0, sizeof(none));
+            tail.flows[pair] = none;
+            __hip_atomic_store(vm.fault, pair + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }

@@ -366,11 +366,12 @@ __global__ __launch_bounds__(kThreads) void k_flow_small_tagged(SmallArgs a, aof
 template <bool SUBPIXEL>
 __global__ __launch_bounds__(kThreads) void k_flow_resident(SmallArgs a, ResidentBox *box, aof_flow *host_record,
                                                             const uint8_t *frame_a, const uint8_t *frame_b, uint32_t served,
-                                                            uint64_t idle_ticks, uint64_t life_ticks)
+                                                            uint32_t launch_no, uint64_t idle_ticks, uint64_t life_ticks)
 {
     __shared__ uint32_t s_req[3];   // request number (0 = leave), slot of the newest frame, buffers to fetch
     __shared__ aof_flow s_record;   // the call's flow record (the kernel's own copy goes to device memory)
     const uint64_t born = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) __hip_atomic_store(&box->started, launch_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     uint64_t idle_since = born;
     uint32_t held[2] = {0u, 0u};    // (thread 0) tag of the request at which LDS buffer b received pinned frame b, 0 = never
     for (;;) {
@@ -456,10 +457,11 @@ bool flow_small_supported(const SmallArgs &a)
 }
 
 int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_record, const uint8_t *frame_a,
-                         const uint8_t *frame_b, uint32_t served, uint64_t idle_ticks, uint64_t life_ticks, void *stream)
+                         const uint8_t *frame_b, uint32_t served, uint32_t launch_no, uint64_t idle_ticks,
+                         uint64_t life_ticks, void *stream)
 {
     if (a.l0.n_pairs != 1 || !flow_small_supported(a)) return (int)hipErrorInvalidValue;
-    void (*fn)(SmallArgs, ResidentBox *, aof_flow *, const uint8_t *, const uint8_t *, uint32_t, uint64_t, uint64_t) =
+    void (*fn)(SmallArgs, ResidentBox *, aof_flow *, const uint8_t *, const uint8_t *, uint32_t, uint32_t, uint64_t, uint64_t) =
         a.l0.subpixel ? k_flow_resident<true> : k_flow_resident<false>;
     const size_t lds = small_lds_bytes(a);
     if (lds > 48 * 1024) {
@@ -468,7 +470,7 @@ int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_re
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(fn, dim3(1), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a, box, host_record, frame_a, frame_b,
-                       served, idle_ticks, life_ticks);
+                       served, launch_no, idle_ticks, life_ticks);
     return (int)hipGetLastError();
 }
 

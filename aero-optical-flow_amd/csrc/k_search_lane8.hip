@@ -60,7 +60,7 @@ __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t item
         const uint32_t pair = live ? fast_div(item, a.div_nb) : 0u;
         aof_block rec;
         rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
-        const int subdir = search_block<SUBPIXEL, PRUNE, EQ>(a, pair, live ? item - __umul24(pair, nb) : 0u, item0, live,
+        const int subdir = search_block<SUBPIXEL, PRUNE, EQ, VOTE && !SUBPIXEL && EQ>(a, pair, live ? item - __umul24(pair, nb) : 0u, item0, live,
                                                              rec, start_row, prune_pays);
         if constexpr (VOTE) {
             // The reduction in the same launch: every lane stays until here and the wave adds its votes
@@ -102,15 +102,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_search_lane8(SearchArgs a, uint
 // The same search with the reduction in the launch: no K3 behind it.  Workgroups [0, search_wgs) search
 // and vote through agent-scope atomics; the workgroups behind them are finalisers, one wave per pair,
 // which wait for their pair's votes and write its flow record (aof_reduce.hpp).
-constexpr uint64_t kVoteDeadlineTicks = 5000000;   // 50 ms of the 100 MHz counter
-
 template <bool SUBPIXEL, bool EQ>
 __global__ __launch_bounds__(kThreads, 4) void k_flow_lane8_flat(SearchArgs a, uint32_t items, uint32_t search_wgs,
                                                                  FlowTail tail, VoteMem votes)
 {
     if (blockIdx.x >= search_wgs) {   // (uniform in the workgroup)
         const uint32_t pair = (blockIdx.x - search_wgs) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        if (pair < (uint32_t)a.n_pairs) await_votes_and_finalise(votes, tail, pair, kVoteDeadlineTicks);
+        if (pair < (uint32_t)a.n_pairs) await_votes_and_finalise(votes, tail, pair);
         return;
     }
     // Every kernel argument the search reads, fetched HERE in one batch of scalar loads: with the
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_flow_lane8(SearchArgs a, FlowTa
     int subdir = 8;
     int start_row = 4, prune_pays = 1;  // (unused: the grouped kernel always searches exhaustively)
     // (a live lane's record index (pair0 + p) * nb + blk is pair0 * nb + tid)
-    if (live) subdir = search_block<SUBPIXEL, false>(a, pair0 + (uint32_t)p, (uint32_t)blk, pair0 * (uint32_t)nb, true, rec,
+    if (live) subdir = search_block<SUBPIXEL, false, true, !SUBPIXEL>(a, pair0 + (uint32_t)p, (uint32_t)blk, pair0 * (uint32_t)nb, true, rec,
                                                      start_row, prune_pays);
     // (the lane's pair is derived again from an opaque copy of its id: nothing of it holds a register
     //  during the search, which sits at the 128 VGPRs of four waves per SIMD)
@@ -238,7 +236,7 @@ static int flat_threads(int64_t items)
 bool lane8_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t capacity_pairs)
 {
     const int n = 2 * (2 * a.hist_range + 1) + 1;
-    if (a.prune || !votes.base || n > 62 || votes.stride < (uint32_t)(2 + 2 * n)) return false;
+    if (a.prune || !votes.base || !votes.fault || n > 62 || votes.stride < (uint32_t)(2 + 2 * n)) return false;
     if (a.grid.blocks() <= 64) return false;   // a wave covers at most two pairs
     const int64_t per = kMaxItems / a.grid.blocks();   // pairs per launch slice
     return (a.n_pairs < per ? a.n_pairs : per) <= capacity_pairs;

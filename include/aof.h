@@ -168,9 +168,18 @@ int aof_set_split_coarse(aof_ctx *ctx, int on);
  * are bit-identical to the separate K3's.  Because the vote memory belongs to the context, calls on
  * ONE context must not overlap on the device: eager calls on different streams are ordered behind each
  * other by the library; captured graphs that contain calls on a context must not be replayed
- * concurrently with each other or with eager calls on it.  on = 0 launches K3 as a separate kernel
- * instead (tests compare the two); 1 = default. */
+ * concurrently with each other or with eager calls on it (once such a graph has been captured, the
+ * library's own eager calls on the context keep to the separate K3).  Launches of more than 2 048 pairs
+ * keep K3 as well.
+ * on = 0 (THE DEFAULT): K3 runs as a separate kernel behind the search.  on = 1: opt in.
+ * A finaliser wave that does not see its pair's votes complete within the deadline (50 ms; a launch in which
+ * that happens is broken) writes that pair's record as "nothing measured" -- flow 0, count 0, quality 0,
+ * flags 0 -- and raises the context's fault word: every later aof_flow_batch_device / aof_flow_pair_host /
+ * aof_stream_push_host on the context returns -EIO (aof_last_error names the pair).  The condition is
+ * sticky, like a HIP fault: recover with a new context. */
 int aof_set_reduce_fusion(aof_ctx *ctx, int on);
+/* Test / diagnostic knob: the finaliser deadline above, in microseconds (default 50 000). */
+int aof_set_vote_deadline_us(aof_ctx *ctx, uint32_t microseconds);
 
 /* ---- host-buffer conveniences (what the C++ facade calls) ----
  * Synchronous: copy in, run the kernels above, copy out.  blocks/subdirs may be NULL. */
@@ -187,10 +196,31 @@ int aof_stream_reset(aof_ctx *ctx);
  * kernel does and posts the 16-byte record and a completion word the host polls -- no launch per frame.
  * The kernel always ends by itself: after 50 ms without a request, after 200 ms in total (so nothing that
  * waits for the device to drain, e.g. a hipFree elsewhere in the process, waits longer), or when the
- * library stops it (aof_destroy, aof_set_*, this call with on = 0); the next call starts it again.  A
- * request that is not answered within 250 ms stops it for good and the call falls back to the graph path.
+ * library stops it (aof_destroy, aof_set_*, this call with on = 0); the next call starts it again.  It runs
+ * on a stream of its own at the highest stream priority, i.e. on a hardware queue that no normal-priority
+ * stream of the process shares.
+ * Every host-side wait of this path is bounded.  A request that is not answered within 250 ms of the
+ * launch call's return (or of the request, when the kernel was already there) switches the mode off for the
+ * context: the kernel is asked to leave and the call, like all later ones, takes the graph path (one line on
+ * stderr, aof_stream_stats.resident_fallbacks, .last_report).  A kernel that does not leave within a second
+ * either keeps its pinned buffers for good (they are leaked, the context continues on fresh ones and the call
+ * returns 1 like the first call of a sequence; aof_destroy then frees no device memory at all).
  * Results are bit-identical in both forms.  on < 0 queries whether the kernel is on the device now. */
 int aof_set_stream_resident(aof_ctx *ctx, int on);
+/* Counters of the streaming entry point since aof_create (diagnostics; tests assert on them). */
+typedef struct aof_stream_stats {
+    uint64_t calls;              /* aof_stream_push_host calls that had a previous frame to compare with */
+    uint64_t resident_served;    /* ... of them answered by the resident kernel */
+    uint32_t resident_launches;  /* resident kernel instances started */
+    uint32_t resident_fallbacks; /* requests it did not answer within 250 ms (resident mode switched off) */
+    uint32_t resident_lost;      /* instances that did not leave within 1 s of being asked (buffers abandoned) */
+    uint32_t tagged_slow;        /* graph path: tagged record not there within 2 ms (the stream was drained instead) */
+    float launch_call_us_max;    /* longest hipLaunchKernelGGL call of a resident start (the first loads the code object) */
+    float start_latency_us_max;  /* longest launch-return -> first-poll latency of a resident kernel, the host only
+                                    spinning on pinned memory in between (no HIP call) */
+    char last_report[320];       /* text of the last fallback report, "" if none */
+} aof_stream_stats;
+int aof_stream_get_stats(const aof_ctx *ctx, aof_stream_stats *out);
 /* The streaming entry point replays a captured hipGraph per call (H2D frame, kernels, the result
  * written into pinned host memory; for frames of at most 64 KB served by the one-workgroup kernel:
  * that ONE kernel reading the pinned frames in place and publishing the record with a tag the host

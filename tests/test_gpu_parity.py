@@ -524,6 +524,95 @@ def test_reduction_inside_the_search_launch_equals_k3(aof, orc, synth, gpu_devic
     eng.close()
 
 
+@pytest.mark.gpu
+def test_a_fresh_context_launches_k3_and_fusion_is_opt_in(aof, synth, gpu_device):
+    """include/aof.h: the reduction inside the search launch is OFF by default.  A fresh context runs K3 as
+    its own kernel (counted by the library's profiling events), aof_set_reduce_fusion(1) removes that launch,
+    0 brings it back; and once a graph holding an in-launch reduction has been captured, the library's own
+    eager launches on that context keep to K3."""
+    import torch
+    p = aof.default_params(320, 240)
+    hp, hc, _ = synth.make_batch(320, 240, 6, 4, 4100)
+    prev, cur = torch.from_numpy(hp).to(gpu_device), torch.from_numpy(hc).to(gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    assert eng.variant == "lane8"
+
+    def k3_launches(call):
+        eng.set_profiling(True)   # (resets the ring)
+        call()
+        torch.cuda.synchronize()
+        n = len(eng.profile_ms(aof.K_REDUCE))
+        eng.set_profiling(False)
+        return n
+
+    _, f_ref, _ = eng.flow_batch(prev, cur)
+    torch.cuda.synchronize()
+    assert k3_launches(lambda: eng.flow_batch(prev, cur)) == 1, "default: K3 is launched behind the search"
+    eng.set_reduce_fusion(True)
+    flows = torch.zeros_like(f_ref)
+    assert k3_launches(lambda: eng.flow_batch(prev, cur, flows=flows)) == 0
+    assert torch.equal(flows, f_ref)
+    eng.set_reduce_fusion(False)
+    assert k3_launches(lambda: eng.flow_batch(prev, cur)) == 1
+    eng.set_reduce_fusion(True)
+    blocks = torch.zeros((6, eng.nblocks(0)), dtype=torch.int32, device=gpu_device)
+    ws = torch.zeros(aof.workspace_layout(p, 6).total_bytes, dtype=torch.uint8, device=gpu_device)
+    eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+    flows.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(flows, f_ref)
+    flows2 = torch.zeros_like(f_ref)
+    assert k3_launches(lambda: eng.flow_batch(prev, cur, flows=flows2)) == 1, \
+        "a captured graph owns the vote records now: eager launches keep to K3"
+    assert torch.equal(flows2, f_ref)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_a_finaliser_deadline_is_an_error_not_a_valid_flow(aof, synth, gpu_device):
+    """The finaliser waves of the in-launch reduction give up after a deadline.  Forced here (deadline 0 on a
+    launch whose last search waves are still running when the first finalisers start): a pair that was given
+    up carries quality 0, count 0 and NO valid flag -- never the all-ones record of round 3 --, every other
+    pair equals K3's record, and every later call on the context returns -EIO naming the condition (sticky;
+    aof_last_error).  A new context works."""
+    import torch
+    p = aof.default_params(640, 480)
+    n = 256
+    hp, hc, _ = synth.make_batch(640, 480, 8, 4, 4200)
+    idx = np.arange(n) % 8
+    prev, cur = torch.from_numpy(hp[idx]).to(gpu_device), torch.from_numpy(hc[idx]).to(gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    _, f_ref, _ = eng.flow_batch(prev, cur)
+    torch.cuda.synchronize()
+    ref = aof.flows_view(f_ref)
+    assert (ref["quality"] > 0).all()
+    eng.set_reduce_fusion(True)
+    eng.set_vote_deadline_us(0)
+    _, flows, _ = eng.flow_batch(prev, cur)
+    torch.cuda.synchronize()
+    got = aof.flows_view(flows)
+    gave_up = [k for k in range(n) if got[k].tobytes() != ref[k].tobytes()]
+    assert gave_up, "deadline 0 on a 256-pair launch: some finaliser must have found its pair incomplete"
+    for k in gave_up:
+        assert got[k].tobytes() == bytes(16), (k, got[k])   # flow 0, count 0, quality 0, flags 0
+    with pytest.raises(aof.AofError) as e:
+        eng.flow_batch(prev, cur)
+    assert e.value.code == -5 and "deadline" in str(e.value) and "pair" in str(e.value)   # -EIO
+    with pytest.raises(aof.AofError):   # sticky
+        eng.flow_pair_host(hp[0], hc[0])
+    eng.close()
+    fresh = aof.FlowEngine(p, 0)
+    _, f2, _ = fresh.flow_batch(prev, cur)
+    torch.cuda.synchronize()
+    assert torch.equal(f2, f_ref)
+    fresh.close()
+
+
 # ---- shapes, options and edge cases ---------------------------------------------
 
 SHAPES = [
@@ -1197,14 +1286,10 @@ def test_resident_kernel_serves_the_streaming_entry_point(aof, orc, synth, gpu_d
             assert got.tobytes() == orc.flow_pair(po, frames[prev], frames[k])["flow"].tobytes(), (k, prev)
         prev = k
         if expect_resident is not None and eng.stream_resident_running() != expect_resident:
-            # The library says on stderr when a request stayed unanswered for 250 ms and it fell back to one
-            # launch per call for good (results stay right, as checked above).  Seen on two consecutive gpurun
-            # calls in round 3 and on no box since: an environment that cannot host the mailbox is no reason
-            # to fail the suite, anything else is.
-            err = capfd.readouterr().err
-            if "the resident kernel did not answer" in err:
-                pytest.skip("the resident kernel did not answer on this box; the launch-per-call fallback gave the oracle's records")
-            raise AssertionError((k, expect_resident, err))
+            # An unanswered request is a failure of this test, with the library's own account of it: the
+            # stderr line and aof_stream_stats (launch call time, launch -> first poll latency, which of
+            # "never started" / "started but silent" / "left" it was).
+            raise AssertionError((k, expect_resident, eng.stream_stats(), capfd.readouterr().err))
 
     push(0)
     for k in range(1, 8):
@@ -1232,7 +1317,12 @@ def test_resident_kernel_serves_the_streaming_entry_point(aof, orc, synth, gpu_d
     for k in range(18, 40):            # 22 more calls; the 200 ms lifetime does not matter to results
         push(k)
     assert eng.stream_resident_running()
+    st = eng.stream_stats()
+    assert st["resident_fallbacks"] == 0 and st["resident_lost"] == 0 and st["tagged_slow"] == 0, st
+    assert st["resident_launches"] >= 4, st   # first start, after the two stops, after the idle exit (+ lifetime restarts)
+    assert st["resident_served"] == 36 and st["calls"] == 38, st   # two frames took the launch-per-call paths
     eng.close()                        # stops the kernel first
+    assert "aof:" not in capfd.readouterr().err
 
 
 def test_streaming_path_follows_kernel_switches_mid_sequence(aof, orc, synth, gpu_device):
