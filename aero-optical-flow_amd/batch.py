@@ -29,11 +29,20 @@ class PendingGather:
     def __init__(self, work, out, n_total, width, world):
         self.work, self.out, self.n_total, self.width, self.world = work, out, n_total, width, world
 
-    def wait_host(self):
-        """Blocks the HOST until the collective has completed (no stream is made to wait)."""
-        if self.work is not None:
-            while not self.work.is_completed():
-                pass
+    def wait_host(self, poll_s=20e-6, timeout_s=60.0):
+        """Blocks the HOST until the collective has completed (no stream is made to wait).  Polls the
+        collective's completion with a short sleep in between -- the caller only asks for gathers that
+        were issued 2 G steps ago, which are done long since, so the first poll normally returns; the
+        sleep keeps a late one from burning the core that launches the next steps.  A collective that
+        does not complete within timeout_s raises (a hung peer must not hang this rank silently)."""
+        import time
+        if self.work is None or self.work.is_completed():
+            return
+        t0 = time.monotonic()
+        while not self.work.is_completed():
+            if time.monotonic() - t0 > timeout_s:
+                raise TimeoutError(f"all_gather of {self.n_total} flow records did not complete within {timeout_s:.0f} s")
+            time.sleep(poll_s)
 
     def wait(self):
         """Blocks the CURRENT STREAM (not the host, on GPUs) until the records have landed

@@ -112,27 +112,47 @@ def spawn_ranks(n):
 def rendezvous_only(args, rank, world):
     """The N>1 control flow of the batched mode with placeholder records and no GPU: every rank
     fills its shard's 16-byte records with the GLOBAL pair index, the ranks gather them, and
-    every rank checks that it sees all pairs in order."""
+    every rank checks that it sees all pairs in order -- for the shape the command line asks for
+    and for the strong shape every N > 1 line also carries (configs3)."""
     import importlib
+    import socket
     import torch.distributed as dist
     ge.load_package()
     batch = importlib.import_module(ge.PKG_NAME + ".batch")
     if world > 1:
         dist.init_process_group("gloo")
+
+    def gathered_in_order(total):
+        b, e = batch.shard_range(total, rank, world)
+        local = torch.arange(b, e, dtype=torch.int32).view(-1, 1).repeat(1, 4).contiguous().view(torch.uint8).view(-1, 16)
+        full = batch.gather_flows(local, total)
+        ok = bool(torch.equal(full.view(torch.int32).view(-1, 4)[:, 0], torch.arange(total, dtype=torch.int32)))
+        if world > 1:
+            t = torch.tensor([1 if ok else 0])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(t.item())
+        return ok, e - b
+
     total = args.pairs if args.scaling == "strong" else args.pairs * world
-    b, e = batch.shard_range(total, rank, world)
-    local = torch.arange(b, e, dtype=torch.int32).view(-1, 1).repeat(1, 4).contiguous().view(torch.uint8).view(-1, 16)
-    full = batch.gather_flows(local, total)
-    ok = bool(torch.equal(full.view(torch.int32).view(-1, 4)[:, 0], torch.arange(total, dtype=torch.int32)))
+    ok, _ = gathered_in_order(total)
+    line = {"rendezvous_only": True, "n_ranks": world, "global_pairs": total, "scaling": args.scaling,
+            "gathered_in_pair_order_on_every_rank": ok}
     if world > 1:
-        t = torch.tensor([1 if ok else 0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = bool(t.item())
+        line["ranks_seen"] = dist.get_world_size()
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cpu ({socket.gethostname()}, no GPU touched)")
+        line["devices"] = names
+        if args.configs3_pairs > 0 and args.configs3_pairs % world == 0:
+            ok3, mine = gathered_in_order(args.configs3_pairs)
+            line["configs3"] = {"global_pairs": args.configs3_pairs, "pairs_per_gpu": mine, "scaling": "strong",
+                                "gathered_in_pair_order_on_every_rank": ok3}
+            ok = ok and ok3
+        else:
+            line["configs3"] = None
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"rendezvous_only": True, "n_ranks": world, "global_pairs": total, "scaling": args.scaling,
-                          "gathered_in_pair_order_on_every_rank": ok}), flush=True)
+        print(json.dumps(line), flush=True)
     return 0 if ok else 1
 
 
@@ -387,6 +407,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the per-step gather even with ONE rank: rehearses the "
                          "N > 1 code path (RCCL, graph capture beside its watchdog thread) on a one-GPU box")
+    ap.add_argument("--configs3-pairs", type=int, default=1024,
+                    help="N > 1: pairs of the strong-scaling shape every multi-GPU line also times (BASELINE configs[3]: "
+                         "1024 pairs sharded over the GPUs, against the same pairs on one GPU); 0 = skip")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="rehearse the N>1 control flow without a GPU: rendezvous, shard, gather a batch of "
                          "placeholder flow records over gloo, print one line and leave (CPU test of the launch path)")
@@ -404,6 +427,10 @@ def main():
         args.gpus = world
     if args.rendezvous_only:
         return rendezvous_only(args, rank, world)
+    if args.backend == "nccl" and torch.cuda.device_count() < world:
+        # one rank per GPU: fail before the rendezvous, with the reason, instead of inside RCCL
+        sys.exit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                 f"(use --backend gloo to rehearse several ranks on the GPUs that exist)")
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -439,16 +466,7 @@ def main():
         reach = args.max_shift
     over = dict(over)
     p = aof.px4flow_params(W, H, **over) if over.pop("_px4flow", 0) else aof.default_params(W, H, **over)
-    eng = aof.FlowEngine(p, dev_index)
 
-    def configure(e):
-        if args.search == "pruned":
-            e.set_search_mode(aof.SEARCH_PRUNED)
-        if args.force_generic:
-            e.force_generic(True)
-        e.set_reduce_fusion(reduce_mode == "fused")
-        if args.coarse != "auto":
-            e.set_split_coarse(True)
     if args.scaling == "strong":
         sb, se = batch.shard_range(args.pairs, rank, world)
         n = se - sb
@@ -456,13 +474,19 @@ def main():
             sys.exit("--scaling strong needs --pairs divisible by the number of GPUs")
     else:
         n = args.pairs
-    launch_bound = aof.abs_diffs(p) * n < 8e9   # a few dozen microseconds of search per step (C2: up to 330 pairs)
-    if args.streams <= 0:
-        args.streams = 2 if launch_bound else 1
-    reduce_mode = args.reduce
-    if reduce_mode == "auto":
-        reduce_mode = "fused" if args.streams > 1 and n <= 512 else "separate"
-    configure(eng)
+
+    def auto_config(n_pairs, streams=0, reduce="auto", graph="auto"):
+        """Lanes, reduction and graph replay for a step of n_pairs pairs per GPU (the automatic choice)."""
+        launch_bound = aof.abs_diffs(p) * n_pairs < 8e9   # a few dozen microseconds of search per step (C2: up to 330 pairs)
+        if streams <= 0:
+            streams = 2 if launch_bound else 1
+        if reduce == "auto":
+            reduce = "fused" if streams > 1 and n_pairs <= 512 else "separate"
+        use_graph = graph == "on" or (graph == "auto" and launch_bound)
+        return dict(streams=streams, reduce_mode=reduce, use_graph=use_graph, launch_bound=launch_bound)
+
+    cfg = auto_config(n, args.streams, args.reduce, args.graph)
+    args.streams, reduce_mode, use_graph, launch_bound = cfg["streams"], cfg["reduce_mode"], cfg["use_graph"], cfg["launch_bound"]
     brightness = args.brightness if args.brightness is not None else (9 if p.mean_subtract else 0)
     prev, cur, shifts = make_batch_gpu(W, H, n, reach, 0xA0F + 7919 * rank, device,
                                        brightness=brightness)
@@ -472,146 +496,182 @@ def main():
         nz = torch.randint(-args.noise, args.noise + 1, cur.shape, generator=g, device=device, dtype=torch.int16)
         cur = (cur.to(torch.int16) + nz).clamp_(0, 255).to(torch.uint8)
         del nz
-    nb = eng.nblocks(0)
-    L = aof.workspace_layout(p, n)
 
-    # A LANE = one context with its own stream, record buffers and workspace; the frames are shared
-    # (read-only).  --streams 1 (default): one lane on torch's current stream, whose two flow buffers
-    # alternate so that the gather of step i overlaps step i+1.  --streams S: step i runs on lane i % S,
-    # so that the launch gaps and the low-occupancy reduction of one batch are covered by the search of
-    # the next one (independent batches in flight on separate HIP streams).
     class Lane:
         pass
-    G = 1
-    if dist is not None:
-        G = args.gather_every if args.gather_every > 0 else (16 if launch_bound else 4)
-    lanes = []
-    for li in range(max(1, args.streams)):
-        ln = Lane()
-        ln.eng = eng if li == 0 else aof.FlowEngine(p, dev_index)
-        if li:
-            configure(ln.eng)
-        ln.stream = torch.cuda.current_stream(device) if args.streams <= 1 else torch.cuda.Stream(device)
-        ln.blocks = torch.empty((n, nb), dtype=torch.int32, device=device)
-        ln.sub = torch.empty((n, nb), dtype=torch.uint8, device=device) if p.subpixel else None
-        ln.ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=device)
-        # The flow records of G consecutive steps of a lane land in one ring segment, and ONE all_gather
-        # per G steps ships it (RCCL and torch's collective call cost 25-40 us of host time and a
-        # cross-queue dependency per call: per step that was +14 us on a 1 024-pair step and made a 128-pair
-        # step host-bound; every step's records still cross xGMI inside the timed region).  Two segments per
-        # lane take turns; the compute stream never WAITS for a gather -- before a segment is written again
-        # the HOST checks that the gather that read it has completed.
-        ln.rings = [torch.empty((G, n, 16), dtype=torch.uint8, device=device) for _ in range(2)]
-        ln.flows = [ln.rings[r][g] for r in range(2) for g in range(G)]
-        ln.reads = [None, None]    # the gather in flight that reads ring segment r
-        ln.gathered = [torch.empty((world * G * n, 16), dtype=torch.uint8, device=device) for _ in range(2)] if dist is not None else None
-        ln.enqueue = [ln.eng.bind_batch(prev, cur, ln.blocks, f, ln.ws, subdirs=ln.sub,
-                                        stream=ln.stream.cuda_stream if args.streams > 1 else None)
-                      for f in ln.flows]   # one ctypes call per step
-        ln.graphs = None
-        ln.i = 0
-        lanes.append(ln)
-    blocks, flows2 = lanes[0].blocks, lanes[0].flows
-    ws = lanes[0].ws
-    state = {"i": 0, "pending": None, "gathered": None, "last": (lanes[0], 0)}
-    multi = len(lanes) > 1
-    use_graph = args.graph == "on" or (args.graph == "auto" and launch_bound)
-    if use_graph:   # a short step is launch-bound: replay it as one hipGraph
-        for ln in lanes:
-            ln.graphs = []
-            for e in ln.enqueue:
-                e()
-                torch.cuda.synchronize(device)
-                g = torch.cuda.CUDAGraph()
-                if multi:
-                    with torch.cuda.graph(g, stream=ln.stream):
-                        e()
-                else:   # (captured on torch's side stream, replayed on the current one)
-                    with torch.cuda.graph(g):
-                        e()
-                ln.graphs.append(g)
 
-    def step():
-        ln = lanes[state["i"] % len(lanes)]
-        k = ln.i % len(ln.flows)
-        ln.i += 1
-        state["i"] += 1
-        state["last"] = (ln, k)
-        r, g = divmod(k, G)
-        if dist is not None and g == 0 and ln.reads[r] is not None:   # (2 G steps of this lane ago: done long since)
-            ln.reads[r].wait_host()
-            ln.reads[r] = None
-        if ln.graphs is not None and not eng_profiling["on"]:
-            if multi:
+    class Runner:
+        """One configuration of the step on this rank.  A LANE = one context with its own stream, record
+        buffers and workspace; the frames are shared (read-only).  streams == 1: one lane on torch's
+        current stream.  streams == S: step i runs on lane i % S, so that the launch gaps and the
+        low-occupancy reduction of one batch are covered by the search of the next one (independent
+        batches in flight on separate HIP streams).  with_dist: the flow records of G consecutive steps
+        of a lane are shipped by ONE all_gather."""
+
+        def __init__(self, prev, cur, streams, reduce_mode, use_graph, launch_bound, with_dist):
+            self.n = n_ = prev.shape[0]
+            self.dist = dist if with_dist else None
+            self.reduce_mode, self.use_graph, self.launch_bound = reduce_mode, use_graph, launch_bound
+            grid = aof.grid(p, 0)
+            nb = grid[4] * grid[5]
+            L = aof.workspace_layout(p, n_)
+            self.G = G = 1 if self.dist is None else (args.gather_every if args.gather_every > 0 else (16 if launch_bound else 4))
+            self.lanes = []
+            for li in range(max(1, streams)):
+                ln = Lane()
+                ln.eng = aof.FlowEngine(p, dev_index)
+                self.configure(ln.eng)
+                ln.stream = torch.cuda.current_stream(device) if streams <= 1 else torch.cuda.Stream(device)
+                ln.blocks = torch.empty((n_, nb), dtype=torch.int32, device=device)
+                ln.sub = torch.empty((n_, nb), dtype=torch.uint8, device=device) if p.subpixel else None
+                ln.ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=device)
+                # The flow records of G consecutive steps of a lane land in one ring segment, and ONE all_gather
+                # per G steps ships it (RCCL and torch's collective call cost 25-40 us of host time and a
+                # cross-queue dependency per call: per step that was +14 us on a 1 024-pair step and made a 128-pair
+                # step host-bound; every step's records still cross xGMI inside the timed region).  Two segments per
+                # lane take turns; the compute stream never WAITS for a gather -- before a segment is written again
+                # the HOST checks that the gather that read it has completed.
+                ln.rings = [torch.empty((G, n_, 16), dtype=torch.uint8, device=device) for _ in range(2)]
+                ln.flows = [ln.rings[r][g] for r in range(2) for g in range(G)]
+                ln.reads = [None, None]    # the gather in flight that reads ring segment r
+                ln.gathered = ([torch.empty((world * G * n_, 16), dtype=torch.uint8, device=device) for _ in range(2)]
+                               if self.dist is not None else None)
+                ln.enqueue = [ln.eng.bind_batch(prev, cur, ln.blocks, f, ln.ws, subdirs=ln.sub,
+                                                stream=ln.stream.cuda_stream if streams > 1 else None)
+                              for f in ln.flows]   # one ctypes call per step
+                ln.graphs = None
+                ln.i = 0
+                self.lanes.append(ln)
+            self.eng = self.lanes[0].eng
+            self.state = {"i": 0, "pending": None, "gathered": None, "last": (self.lanes[0], 0)}
+            self.multi = len(self.lanes) > 1
+            self.profiling = False
+            if use_graph:   # a short step is launch-bound: replay it as one hipGraph
+                for ln in self.lanes:
+                    ln.graphs = []
+                    for e in ln.enqueue:
+                        e()
+                        torch.cuda.synchronize(device)
+                        g = torch.cuda.CUDAGraph()
+                        if self.multi:
+                            with torch.cuda.graph(g, stream=ln.stream):
+                                e()
+                        else:   # (captured on torch's side stream, replayed on the current one)
+                            with torch.cuda.graph(g):
+                                e()
+                        ln.graphs.append(g)
+
+        def configure(self, e):
+            if args.search == "pruned":
+                e.set_search_mode(aof.SEARCH_PRUNED)
+            if args.force_generic:
+                e.force_generic(True)
+            e.set_reduce_fusion(self.reduce_mode == "fused")
+            if args.coarse != "auto":
+                e.set_split_coarse(True)
+
+        def set_profiling(self, on, kernels=None):
+            self.profiling = bool(on)
+            self.eng.set_profiling(on, kernels=kernels) if kernels is not None else self.eng.set_profiling(on)
+
+        def step(self):
+            state, lanes, G, n_ = self.state, self.lanes, self.G, self.n
+            ln = lanes[state["i"] % len(lanes)]
+            k = ln.i % len(ln.flows)
+            ln.i += 1
+            state["i"] += 1
+            state["last"] = (ln, k)
+            r, g = divmod(k, G)
+            if self.dist is not None and g == 0 and ln.reads[r] is not None:   # (2 G steps of this lane ago: done long since)
+                ln.reads[r].wait_host()
+                ln.reads[r] = None
+            if ln.graphs is not None and not self.profiling:
+                if self.multi:
+                    torch.cuda.set_stream(ln.stream)
+                ln.graphs[k].replay()
+            else:
+                ln.enqueue[k]()
+            if self.dist is None or g != G - 1:
+                return
+            if self.multi:
                 torch.cuda.set_stream(ln.stream)
-            ln.graphs[k].replay()
-        else:
-            ln.enqueue[k]()
-        if dist is None:
-            return
-        if g != G - 1:
-            return
-        if multi:
-            torch.cuda.set_stream(ln.stream)
-        seg = ln.rings[r].view(G * n, 16)
-        src = seg.cpu() if args.backend == "gloo" else seg  # gloo (rehearsal) gathers host copies
-        state["pending"] = batch.gather_flows_async(src, world * G * n, force=args.force_dist,
-                                                    out=ln.gathered[r] if args.backend == "nccl" else None)
-        ln.reads[r] = state["pending"]
+            seg = ln.rings[r].view(G * n_, 16)
+            src = seg.cpu() if args.backend == "gloo" else seg  # gloo (rehearsal) gathers host copies
+            state["pending"] = batch.gather_flows_async(src, world * G * n_, force=args.force_dist,
+                                                        out=ln.gathered[r] if args.backend == "nccl" else None)
+            ln.reads[r] = state["pending"]
 
-    eng_profiling = {"on": False}
-    _set_prof = eng.set_profiling
+        def drain(self):
+            for ln in self.lanes:
+                for k, g in enumerate(ln.reads):
+                    if g is not None:
+                        g.wait_host()
+                        ln.reads[k] = None
+            if self.state["pending"] is not None:
+                self.state["gathered"] = self.state["pending"].wait()
+                self.state["pending"] = None
 
-    def set_profiling(on, kernels=None):
-        eng_profiling["on"] = bool(on)
-        _set_prof(on, kernels=kernels) if kernels is not None else _set_prof(on)
-    eng.set_profiling = set_profiling
-
-    def drain():
-        for ln in lanes:
-            for k, g in enumerate(getattr(ln, "reads", [])):
-                if g is not None:
-                    g.wait_host()
-                    ln.reads[k] = None
-        if state["pending"] is not None:
-            state["gathered"] = state["pending"].wait()
-            state["pending"] = None
-
-    def fence():
-        drain()
-        torch.cuda.synchronize(device)
-        if dist is not None:
-            dist.barrier()
+        def fence(self):
+            self.drain()
             torch.cuda.synchronize(device)
+            if self.dist is not None:
+                self.dist.barrier()
+                torch.cuda.synchronize(device)
 
-    # Untimed settling phase before the W warm-up steps: the device's clocks take tens of
-    # milliseconds of sustained load to settle (measured: K2 0.251 ms in a cold 20-step run,
-    # 0.227 ms after 150 ms of load), and W is often only a handful of steps.  A fixed number of
-    # steps, so that every rank issues the same collectives.
-    for i in range(args.settle_steps):
-        step()
-        if i % 50 == 49:
-            drain()
-            torch.cuda.synchronize(device)
-    fence()
+        def settle(self, steps):
+            # Untimed settling phase: the device's clocks take tens of milliseconds of sustained load to
+            # settle (measured: K2 0.251 ms in a cold 20-step run, 0.227 ms after 150 ms of load).  A fixed
+            # number of steps, so that every rank issues the same collectives.
+            for i in range(steps):
+                self.step()
+                if i % 50 == 49:
+                    self.drain()
+                    torch.cuda.synchronize(device)
+            self.fence()
+
+        def timed(self, steps):
+            """EXACTLY `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+            self.fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.fence()
+            elapsed = time.perf_counter() - t0
+            if self.dist is not None:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            return elapsed
+
+        def close(self):
+            self.fence()
+            if self.multi:
+                torch.cuda.set_stream(torch.cuda.default_stream(device))
+            for ln in self.lanes:
+                ln.graphs = None
+                ln.eng.close()
+
+    run = Runner(prev, cur, args.streams, reduce_mode, use_graph, launch_bound, with_dist=dist is not None)
+    eng, lanes, state, multi, G = run.eng, run.lanes, run.state, run.multi, run.G
+    nb = eng.nblocks(0)
+    blocks = lanes[0].blocks
+    step, fence, drain = run.step, run.fence, run.drain
+    eng_set_profiling = run.set_profiling
+
+    run.settle(args.settle_steps)   # (W is often only a handful of steps)
     # HIP events around the dominant kernel (K2, level 0) on the launch stream.  Steps of a millisecond
     # or so carry them inside the timed region; every event pair costs the stream a few microseconds of
     # serialisation, so short steps (and replayed graphs, several lanes) are timed
     # without events and K2 is measured in a second pass of the same K steps on lane 0 right after it.
-    eng.set_profiling(True, kernels=[aof.K_SEARCH])
+    eng_set_profiling(True, kernels=[aof.K_SEARCH])
     lanes[0].enqueue[0]()
     fence()
     lps = max(1, len(eng.profile_ms(aof.K_SEARCH)))   # K2 launches per step (a batch of more than 2^31 blocks is cut into several)
     events_in_timed_region = lps == 1 and not use_graph and not multi and not launch_bound
-    eng.set_profiling(events_in_timed_region, kernels=[aof.K_SEARCH])
+    eng_set_profiling(events_in_timed_region, kernels=[aof.K_SEARCH])
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = run.timed(args.steps)
     # Per-step times for the median: a further pass of the same K steps with one event behind every step
     # (outside the timed region, so that `value` is not taxed with the event records).
     marks = []
@@ -629,26 +689,22 @@ def main():
     if multi:
         torch.cuda.set_stream(torch.cuda.default_stream(device))
     if not events_in_timed_region:
-        eng.set_profiling(True, kernels=[aof.K_SEARCH])
+        eng_set_profiling(True, kernels=[aof.K_SEARCH])
         for _ in range(args.steps):
             lanes[0].enqueue[0]()
         fence()
-    eng.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    eng_set_profiling(False)
 
     # ---- dominant kernel against its roofline (rank 0's launches) ----
     # (the event ring keeps the last 256 launches: whole steps only)
     k2 = eng.profile_ms(aof.K_SEARCH)
     k2 = k2[len(k2) - min(args.steps, len(k2) // lps) * lps:]
     k2_ms = float(np.sum(k2)) / (len(k2) // lps) if k2 else float("nan")
-    eng.set_profiling(True)          # all kernels, outside the timed region
+    eng_set_profiling(True)          # all kernels, outside the timed region
     for _ in range(5):
         lanes[0].enqueue[0]()
     fence()
-    eng.set_profiling(False)
+    eng_set_profiling(False)
     per_kernel = {}
     for name, kid in (("pyramid", aof.K_PYRAMID), ("search_l1", aof.K_SEARCH_L1),
                       ("reduce_l1", aof.K_REDUCE_L1), ("search", aof.K_SEARCH), ("reduce", aof.K_REDUCE)):
@@ -659,6 +715,65 @@ def main():
         # the AOF_K_PYRAMID bracket timed k_coarse: sums + pyramid + level-1 search + level-1 reduction
         per_kernel["coarse_fused"] = per_kernel.pop("pyramid")
     per_kernel["search"] = round(k2_ms, 5)  # the timed region's own measurement
+    # ---- BASELINE configs[3] on every N > 1 line, whatever --scaling says: the STRONG shape ----
+    # (--configs3-pairs, default 1 024, sharded over the ranks: 128 per GPU at N = 8, run as the automatic
+    # choice runs it -- two lanes, graph replay, reduction in the search launch -- with the gather inside the
+    # timed region; beside it the one-GPU step over ALL of those pairs, timed on rank 0 of the same job, so
+    # that the line itself answers "how many times faster than one GPU is the sharded batch")
+    configs3 = None
+    ranks_seen, devices_seen = 1, None
+    if dist is not None:
+        ranks_seen = dist.get_world_size()
+        props = torch.cuda.get_device_properties(device)
+        mine = f"rank {rank}: cuda:{dev_index} {props.name} ({getattr(props, 'gcnArchName', '?')}, {props.total_memory >> 30} GiB)"
+        devices_seen = [None] * ranks_seen
+        dist.all_gather_object(devices_seen, mine)
+    if dist is not None and args.configs3_pairs > 0:
+        total3 = args.configs3_pairs
+        if total3 % world:
+            configs3 = {"skipped": f"{total3} pairs do not divide over {world} ranks"}
+        else:
+            n3 = total3 // world
+            c3 = auto_config(n3)
+            steps3 = args.steps
+            if args.scaling == "strong" and args.pairs == total3 and cfg == auto_config(n):
+                ms3 = elapsed / args.steps * 1e3   # the main region IS this shape
+            else:
+                if n3 <= n:
+                    prev3, cur3 = prev[:n3], cur[:n3]
+                else:
+                    prev3, cur3, _ = make_batch_gpu(W, H, n3, reach, 0xC3 + 7919 * rank, device, brightness=brightness)
+                r3 = Runner(prev3, cur3, c3["streams"], c3["reduce_mode"], c3["use_graph"], c3["launch_bound"], with_dist=True)
+                r3.settle(min(args.settle_steps, 200))
+                for _ in range(args.warmup):
+                    r3.step()
+                ms3 = r3.timed(steps3) / steps3 * 1e3
+                r3.close()
+                del r3, prev3, cur3
+            # the one-GPU reference: all total3 pairs on rank 0's GPU, the configuration the N = 1 line runs
+            ms1 = None
+            if rank == 0:
+                if total3 <= n:
+                    prev1, cur1 = prev[:total3], cur[:total3]
+                else:
+                    prev1, cur1, _ = make_batch_gpu(W, H, total3, reach, 0xA0F, device, brightness=brightness)
+                c1 = auto_config(total3)
+                r1 = Runner(prev1, cur1, c1["streams"], c1["reduce_mode"], c1["use_graph"], c1["launch_bound"], with_dist=False)
+                r1.settle(min(args.settle_steps, 200))
+                for _ in range(args.warmup):
+                    r1.step()
+                ms1 = r1.timed(steps3) / steps3 * 1e3
+                r1.close()
+                del r1, prev1, cur1
+            dist.barrier()
+            configs3 = {"global_pairs": total3, "pairs_per_gpu": n3, "steps": steps3, "ms_per_step": round(ms3, 5),
+                        "value": round(total3 / (ms3 * 1e-3), 1), "unit": "frame-pairs/s", "scaling": "strong",
+                        "streams": c3["streams"], "reduce": c3["reduce_mode"], "graph_replay": bool(c3["use_graph"]),
+                        "one_gpu_ms_per_step": round(ms1, 5) if ms1 else None,
+                        "one_gpu_value": round(total3 / (ms1 * 1e-3), 1) if ms1 else None,
+                        "vs_one_gpu_1024": round(ms1 / ms3, 3) if ms1 else None,
+                        "note": f"{total3} pairs sharded over {world} ranks with the flow records gathered on every rank, "
+                                f"against the same {total3} pairs on rank 0's GPU alone (same job, same clock)"}
     alg_bytes = aof.algorithmic_bytes(p)
     achieved = alg_bytes * n / (k2_ms * 1e-3) / 1e9
     # `traffic` is NOT measured in this run: PMC counters need rocprofv3 around the process.  It is
@@ -705,6 +820,10 @@ def main():
                      if not args.search.startswith("pruned") else None},
         "kernels_ms": per_kernel,
     }
+    if dist is not None:
+        out["ranks_seen"] = ranks_seen
+        out["devices"] = devices_seen
+        out["configs3"] = configs3
 
     # ---- secondary, clearly separate: the opt-in exact-pruning search on the same batch ----
     # (same records bit for bit; data-dependent rate, so never the headline `value`)
