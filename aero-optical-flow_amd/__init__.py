@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOF_LIB") or os.path.join(_HERE, "csrc", "libaof.so")
 
 GRID_DENSE, GRID_PX4FLOW = 0, 1
-SEARCH_EXHAUSTIVE, SEARCH_PRUNED = 0, 1
+SEARCH_EXHAUSTIVE, SEARCH_PRUNED, SEARCH_ADAPTIVE = 0, 1, 2
 SAD_SKIPPED = 0xFFFF
 FLAG_FLOW_VALID, FLAG_PRED_VALID = 1, 2
 K_PYRAMID, K_SEARCH_L1, K_REDUCE_L1, K_SEARCH, K_REDUCE = range(5)
@@ -63,7 +63,7 @@ GYRO_DTYPE = np.dtype([("integ_x", "<f4"), ("integ_y", "<f4"), ("integ_z", "<f4"
 class WsLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "sums", "l1_prev", "l1_cur", "l1_blocks", "l1_subdirs", "l1_flows",
-        "l0_blocks", "l0_subdirs", "l0_hist", "l1_hist")]
+        "l0_blocks", "l0_subdirs", "l0_hist", "l1_hist", "hints")]
 
 
 class StreamStats(C.Structure):
@@ -111,6 +111,7 @@ def _load():
         "aof_search_variant": (C.c_char_p, [VP]),
         "aof_set_force_generic": (C.c_int, [VP, C.c_int]),
         "aof_set_search_mode": (C.c_int, [VP, C.c_int]),
+        "aof_get_search_mode": (C.c_int, [VP]),
         "aof_set_split_coarse": (C.c_int, [VP, C.c_int]),
         "aof_set_reduce_fusion": (C.c_int, [VP, C.c_int]),
         "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
@@ -271,8 +272,13 @@ class FlowEngine:
         self._check(lib.aof_set_force_generic(self._ctx, int(on)))
 
     def set_search_mode(self, mode):
-        """SEARCH_EXHAUSTIVE (default) or SEARCH_PRUNED (exact, data-dependent rate)."""
+        """SEARCH_EXHAUSTIVE (default for 8x8 tiles), SEARCH_PRUNED (exact, data-dependent rate) or
+        SEARCH_ADAPTIVE (default for 16x16 tiles: pruned where a probe of the block row says it pays)."""
         self._check(lib.aof_set_search_mode(self._ctx, int(mode)))
+
+    @property
+    def search_mode(self) -> int:
+        return lib.aof_get_search_mode(self._ctx)
 
     def set_split_coarse(self, on=True):
         """Two-level batches: run K1 / level-1 search / level-1 reduce as separate kernels (fills the

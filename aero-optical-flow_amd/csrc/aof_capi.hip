@@ -217,7 +217,10 @@ SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const
     a.blocks = blocks; a.subdirs = p.subpixel ? subdirs : nullptr;
     a.pred = pred; a.sums = sums; a.level = level; a.n_pairs = n;
     a.hist_range = level_range(p, level);
-    a.prune = ctx->search_mode == AOF_SEARCH_PRUNED;
+    // 0 exhaustive, 1 pruned, 2 adaptive (16x16: a probe kernel judges every pair first; the 8x8 pruned
+    // kernel decides per wave already, so both opt-in modes select it)
+    a.prune = ctx->search_mode;
+    a.hints = nullptr;   // (16x16 searches: set from the workspace by enqueue_coarse / enqueue_fine)
     return a;
 }
 
@@ -301,6 +304,7 @@ struct BatchView {
     uint8_t *l1_prev, *l1_cur;
     aof_block *blocks1; uint8_t *subdirs1; aof_flow *flows1; uint8_t *hist1;
     aof_block *blocks0; uint8_t *subdirs0; aof_flow *flows; uint8_t *hist0;
+    uint32_t *hints;   // 16x16 adaptive search: per-pair verdicts (both levels use it, one after the other)
 };
 
 FlowTail flow_tail(const aof_ctx *ctx, int level, aof_flow *flows, const aof_flow *pred)
@@ -382,6 +386,7 @@ int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, h
     const int64_t nb1 = ctx->g1.blocks();
     SearchArgs sa = search_args(ctx, 1, a.l1_prev, a.l1_cur, l1_frame, v.blocks1 + first * nb1,
                                 v.subdirs1 ? v.subdirs1 + first * nb1 : nullptr, nullptr, sums, n);
+    sa.hints = v.hints ? v.hints + first : nullptr;
     return enqueue_level(ctx, 1, sa, flow_tail(ctx, 1, v.flows1 + first, nullptr),
                          v.hist1 + (size_t)first * hist_bytes_per_pair(p, 1), AOF_K_SEARCH_L1, AOF_K_REDUCE_L1, s);
 }
@@ -396,6 +401,7 @@ int enqueue_fine(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, hip
     SearchArgs sa = search_args(ctx, 0, v.prev + first * v.stride, v.cur + first * v.stride, v.stride,
                                 v.blocks0 + first * nb0, v.subdirs0 ? v.subdirs0 + first * nb0 : nullptr, pred,
                                 v.sums ? v.sums + first * 4 : nullptr, n);
+    sa.hints = v.hints ? v.hints + first : nullptr;
     return enqueue_level(ctx, 0, sa, flow_tail(ctx, 0, v.flows + first, pred),
                          v.hist0 + (size_t)first * hist_bytes_per_pair(p, 0), AOF_K_SEARCH, AOF_K_REDUCE, s);
 }
@@ -421,6 +427,7 @@ BatchView batch_view(const aof_ctx *ctx, const aof_ws_layout &L, const uint8_t *
     if (p.subpixel) v.subdirs0 = d_subdirs ? d_subdirs : ws + L.l0_subdirs;
     v.flows = d_flows;
     v.hist0 = ws + L.l0_hist;
+    v.hints = p.tile == 16 ? reinterpret_cast<uint32_t *>(ws + L.hints) : nullptr;
     return v;
 }
 
@@ -536,6 +543,8 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
     }
     ctx->vote_deadline_ticks = kVoteDeadlineTicks;
     ctx->separate_reduce = true;   // the in-launch reduction is opt-in (aof_set_reduce_fusion)
+    // 16x16 tiles: exact pruning wherever the block row's own probe says it pays (include/aof.h)
+    ctx->search_mode = p->tile == 16 ? AOF_SEARCH_ADAPTIVE : AOF_SEARCH_EXHAUSTIVE;
 
     *out = ctx;
     return 0;
@@ -591,6 +600,8 @@ void aof_destroy(aof_ctx *ctx)
 
 const char *aof_last_error(const aof_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
+int aof_get_search_mode(const aof_ctx *ctx) { return ctx ? ctx->search_mode : -EINVAL; }
+
 int aof_get_params(const aof_ctx *ctx, aof_params *out)
 {
     if (!ctx || !out) return -EINVAL;
@@ -637,7 +648,7 @@ int aof_set_force_generic(aof_ctx *ctx, int on)
 
 int aof_set_search_mode(aof_ctx *ctx, int mode)
 {
-    if (!ctx || mode < AOF_SEARCH_EXHAUSTIVE || mode > AOF_SEARCH_PRUNED) return -EINVAL;
+    if (!ctx || mode < AOF_SEARCH_EXHAUSTIVE || mode > AOF_SEARCH_ADAPTIVE) return -EINVAL;
     { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }   // it runs the kernels chosen so far
     if (mode != ctx->search_mode) drop_push_graphs(ctx);
     ctx->search_mode = mode;

@@ -82,7 +82,8 @@ struct SearchArgs {
     int32_t level;             // which sums column to use
     int64_t n_pairs;
     int32_t hist_range;        // R
-    int32_t prune;             // exact partial-distortion elimination (lane8, tile16)
+    int32_t prune;             // 0 exhaustive, 1 exact partial-distortion elimination (lane8, tile16), 2 adaptive (tile16: per pair, by hints)
+    uint32_t *hints;           // tile16, adaptive: [n_pairs] written by its probe kernel (1 = pruning pays), workspace
     FastDiv div_nb, div_nx;    // lane8: filled by its launchers (item -> pair, block -> row)
 };
 

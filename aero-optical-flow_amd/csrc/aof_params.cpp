@@ -197,6 +197,7 @@ int aof_workspace_layout(const aof_params *p, int64_t n_pairs, aof_ws_layout *ou
         (level ? out->l1_hist : out->l0_hist) = off;
         off = align_up(off + n * hist_bytes_per_pair(*p, level), 256);
     }
+    out->hints = off;       off = align_up(off + (p->tile == 16 ? n * sizeof(uint32_t) : 0), 256);
     out->total_bytes = off ? off : 256;
     return 0;
 }

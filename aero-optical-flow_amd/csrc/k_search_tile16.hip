@@ -27,6 +27,14 @@ namespace {
 constexpr int kThreads = 512;
 constexpr int kSide = 17;  // 2S+1
 constexpr int kBoundRows = 2;  // tile rows summed for the lower bound of the pruned search
+// ADAPTIVE mode (the default of 16x16 contexts): the probe kernel below decides per pair.
+constexpr int kProbeThreads = 1024;        // a pair's ~1 200 probe items in two rounds
+constexpr int kProbeStride = 8;            // every eighth block in x and in y is probed (VGA-like grids: ~1.6 % of the blocks)
+constexpr int kProbeMaxBlocks = 128;       // sample blocks per pair at the most (the stride grows beyond that)
+// (thresholds from a same-box sweep over sensor noise 0 .. 40 LSB, profiles/r04_c5_adaptive_thresholds.txt: with
+//  6 x / 35 % the mode follows the faster of the two fixed modes within 5 % at every noise level but one, 8 %)
+constexpr uint32_t kFullOverBound = 6;     // a row can survive when its two-row bound <= this x the block's smallest bound
+constexpr uint32_t kMaxSurvivorsPct = 35;  // more predicted survivors than this: the exhaustive scan is faster
 constexpr int kRefineParts = 4;  // lanes per block in the half-pixel refinement (1: 3.56, 2: 3.31, 4: 3.28 ms per 1 024 c5h pairs)
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
@@ -41,7 +49,7 @@ __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)h
 // packed u16) and acc16 (offset 16 in the high half, on top of what the caller put there).
 template <int NR, int STEP>
 __device__ __forceinline__ void sum_item(const uint8_t *s_prev, const uint8_t *s_cur, int W, int dyi, int bx, int xs,
-                                         int first, u64 (&acc)[4], uint32_t &acc16)
+                                         int first, u64 (&acc)[4], uint32_t &acc16, int delta = 0)
 {
     // reference tile rows: 4 dwords at frame column 16*bx + 8
     uint32_t ref[NR][4];
@@ -55,7 +63,8 @@ __device__ __forceinline__ void sum_item(const uint8_t *s_prev, const uint8_t *s
 #pragma unroll
     for (int i = 0; i < NR; i++) {
         const uint4 *p = reinterpret_cast<const uint4 *>(win + (size_t)(i * STEP) * W);
-        const uint4 q0 = p[0], q1 = p[1];
+        uint4 q0 = p[0], q1 = p[1];
+        if (delta != 0) { q0 = sat_add_u8x16(q0, delta); q1 = sat_add_u8x16(q1, delta); }   // (the probe: raw frames)
         const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
         u64 pr[7];
 #pragma unroll
@@ -86,11 +95,11 @@ __device__ __forceinline__ uint32_t row_key(const u64 (&acc)[4], uint32_t acc16,
 
 template <int NR, int STEP>
 __device__ __forceinline__ uint32_t eval_item(const uint8_t *s_prev, const uint8_t *s_cur, int W, int dyi, int bx, int xs,
-                                              int first)
+                                              int first, int delta = 0)
 {
     u64 acc[4] = {0, 0, 0, 0};
     uint32_t acc16 = (uint32_t)(dyi * kSide + 16);  // offset 16 as sad<<16 | idx
-    sum_item<NR, STEP>(s_prev, s_cur, W, dyi, bx, xs, first, acc, acc16);
+    sum_item<NR, STEP>(s_prev, s_cur, W, dyi, bx, xs, first, acc, acc16, delta);
     return row_key(acc, acc16, dyi);
 }
 
@@ -236,6 +245,21 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         uint16_t *s_list = s_pmin + kSide * nx;                                 // [17 * nx] item ids
         uint32_t *s_count = reinterpret_cast<uint32_t *>(s_list + kSide * nx);   // (2 * 34 * nx bytes: dword-aligned)
         if (tid == 0) *s_count = 0;
+        // ADAPTIVE (a.prune == 2): the probe kernel in front of this launch has judged the pair (a.hints):
+        // 0 = its candidates look alike (sensor noise: nothing could be dropped and the pruned steps would
+        // cost 1.5x the exhaustive scan), so the workgroup runs the exhaustive scan; the records are the same.
+        typedef const __attribute__((address_space(4))) uint32_t *const_u32;   // (scalar load: uniform in the workgroup)
+        const bool pays = a.prune != 2 || ((const_u32)a.hints)[pair] != 0u;
+        if (!pays) {
+            for (int item = tid; item < items; item += kThreads) {
+                const int dyi = item / nx, bx = item - dyi * nx;
+                const int xf = 16 * bx + px;
+                if (xf < 0 || xf + 32 > Wb) continue;
+                atomicMin(&s_best[bx], eval_item<16, 1>(s_prev, s_cur, W, dyi, bx, xf - sh, 0));
+            }
+        }
+        const int items_all = items;
+        const int items = pays ? items_all : 0;   // (the pruned steps below then have nothing to do)
         for (int item = tid; item < items; item += kThreads) {
             const int dyi = item / nx, bx = item - dyi * nx;
             const int xf = 16 * bx + px;
@@ -246,7 +270,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         __syncthreads();
         // (four lanes per block, four interleaved tile rows each, sums joined across the quad: the
         //  step is one item's latency long whatever the lane count, so it is kept a quarter item)
-        for (int q = tid; q < (rows_ok ? 4 * ((nx + 15) / 16 * 16) : 0); q += kThreads) {   // whole waves: shuffles
+        for (int q = tid; q < (rows_ok && pays ? 4 * ((nx + 15) / 16 * 16) : 0); q += kThreads) {   // whole waves: shuffles
             const int bx = q >> 2, part = q & 3;
             const int xf = 16 * bx + px;
             const bool in = bx < nx && !(xf < 0 || xf + 32 > Wb);
@@ -404,6 +428,60 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     }
 }
 
+// The probe of the ADAPTIVE mode: ONE workgroup per pair takes every kProbeStride-th block in x and y,
+// computes the two-row lower bounds of its 17 dy rows straight from global memory (what step A of the pruned
+// search computes for every block; here for 1.6 % of them), and estimates how many (dy, block) items
+// would survive the bounds: a row survives when its bound does not exceed kFullOverBound times the block's
+// smallest bound -- the complete SAD of the best row is several times its two-row share (up to 8x when the
+// residual is noise), and a row whose bound already exceeds the best complete SAD can be dropped.  More than
+// kMaxSurvivorsPct of them: hints[pair] = 0 (run the exhaustive scan), else 1.  A heuristic about SPEED
+// only: both branches of the search kernel write the same records.
+__global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, uint32_t *hints, int stride)
+{
+    __shared__ uint16_t s_bound[kProbeMaxBlocks][kSide + 1];
+    __shared__ uint32_t s_tot[2];
+    const int64_t pair = blockIdx.x;
+    const int tid = threadIdx.x, W = a.w, nx = a.grid.nx, ny = a.grid.ny;
+    const int sx = (nx + stride - 1 - stride / 2) / stride, sy = (ny + stride - 1 - stride / 2) / stride;   // blocks stride/2, + stride, ...
+    const int nsamp = sx * sy;   // <= kProbeMaxBlocks (launcher)
+    const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * a.h));
+    int px = 0, py = 0;
+    if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
+    const int org = a.grid.x0 - 8;
+    const int H = a.h - 2 * org, Wb = W - 2 * org;
+    const uint8_t *prev = a.prev + pair * a.pair_stride + (int64_t)org * (W + 1);
+    const uint8_t *cur = a.cur + pair * a.pair_stride + (int64_t)org * (W + 1);
+    if (tid < 2) s_tot[tid] = 0;
+    for (int s = tid; s < kSide * nsamp; s += kProbeThreads) {
+        const int blk = s / kSide, dyi = s - blk * kSide;
+        const int by = (blk / sx) * stride + stride / 2, bx = (blk % sx) * stride + stride / 2;
+        const int xf = 16 * bx + px, yc0 = 16 * by + py;
+        uint32_t bound = 0xFFFFu;
+        if (xf >= 0 && xf + 32 <= Wb && yc0 >= 0 && yc0 + 32 <= H)
+            bound = eval_item<kBoundRows, 16 / kBoundRows>(prev + (int64_t)(16 * by + 8) * W, cur + (int64_t)yc0 * W, W, dyi, bx, xf,
+                                                           8 / kBoundRows, delta) >> 16;
+        s_bound[blk][dyi] = (uint16_t)bound;
+    }
+    __syncthreads();
+    uint32_t would_survive = 0, rows = 0;
+    for (int blk = tid; blk < nsamp; blk += kProbeThreads) {
+        uint32_t m = 0xFFFFu;
+#pragma unroll
+        for (int d = 0; d < kSide; d++) m = min(m, (uint32_t)s_bound[blk][d]);
+        if (m == 0xFFFFu) continue;   // window outside the frame: the block is skipped anyway
+        const uint32_t limit = kFullOverBound * m;
+#pragma unroll
+        for (int d = 0; d < kSide; d++) would_survive += (uint32_t)s_bound[blk][d] <= limit ? 1u : 0u;
+        would_survive -= 1;            // (the best row itself is evaluated completely either way)
+        rows += kSide - 1;
+    }
+    would_survive = wave_sum_u32(would_survive);
+    rows = wave_sum_u32(rows);
+    if ((tid & 63) == 0) { atomicAdd(&s_tot[0], would_survive); atomicAdd(&s_tot[1], rows); }
+    __syncthreads();
+    if (tid == 0) hints[pair] = (s_tot[1] != 0 && 100u * s_tot[0] > kMaxSurvivorsPct * s_tot[1]) ? 0u : 1u;
+}
+
 size_t tile16_lds(const SearchArgs &a)
 {
     size_t bytes = (size_t)48 * a.w + 4 * (size_t)a.grid.nx + 16;
@@ -433,6 +511,17 @@ int launch_search_tile16(const SearchArgs &a, void *stream)
     if (a.n_pairs == 0) return 0;
     const int64_t total = a.n_pairs * a.grid.ny;
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
+    if (a.prune == 2) {   // ADAPTIVE: judge every pair first (hints in the workspace), then the search decides per pair
+        if (!a.hints) return (int)hipErrorInvalidValue;
+        int stride = kProbeStride;
+        auto samples = [&](int st) { return ((a.grid.nx + st - 1 - st / 2) / st) * ((a.grid.ny + st - 1 - st / 2) / st); };
+        while (samples(stride) > kProbeMaxBlocks) stride *= 2;
+        while (stride > 1 && samples(stride) == 0) stride /= 2;   // (small grids: every block)
+        hipLaunchKernelGGL(k_tile16_probe, dim3((uint32_t)a.n_pairs), dim3(kProbeThreads), 0, static_cast<hipStream_t>(stream), a,
+                           a.hints, stride);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
     const size_t lds = tile16_lds(a);
     void (*fn)(SearchArgs, uint32_t) =
         tile16_refines(a) ? (a.prune ? k_search_tile16<true, true> : k_search_tile16<false, true>)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AOF_VERSION 100 /* 0.1.0 */
+#define AOF_VERSION 101 /* 0.1.1: aof_ws_layout.hints, aof_stream_stats, search mode ADAPTIVE */
 
 #define AOF_GRID_DENSE 0   /* origin = margin, step = tile */
 #define AOF_GRID_PX4FLOW 1 /* published sparse grid: num_blocks tiles per axis */
@@ -88,6 +88,7 @@ typedef struct aof_ws_layout {
     size_t l0_subdirs;/* u8 [n_pairs][nb0] when the caller passes none */
     size_t l0_hist;   /* u32 [n_pairs][chunks0][2][bins0]: per-chunk vote histograms (grids beyond 8 192 blocks) */
     size_t l1_hist;   /* u32 [n_pairs][chunks1][2][bins1] */
+    size_t hints;     /* u32 [n_pairs], 16x16 tiles: the adaptive search's per-pair verdict (1 = pruning pays) */
 } aof_ws_layout;
 
 typedef struct aof_ctx aof_ctx;
@@ -124,17 +125,24 @@ int aof_get_params(const aof_ctx *ctx, aof_params *out);
 const char *aof_search_variant(const aof_ctx *ctx);
 /* Force the generic search kernel (tests compare the two device paths). */
 int aof_set_force_generic(aof_ctx *ctx, int on);
-/* Search strategy.  Both return bit-identical records.
- * EXHAUSTIVE (default): all candidates of every block are summed completely -- a data-independent
- *   rate, the one BASELINE's metric is quoted on.
+/* Search strategy.  All return bit-identical records.
+ * EXHAUSTIVE (default for 8x8 tiles): all candidates of every block are summed completely -- a
+ *   data-independent rate, the one BASELINE's metric is quoted on.
  * PRUNED: exact partial-distortion elimination (8x8 tiles on grids of more than 256 blocks, and
  *   16x16 tiles).  The dy rows are visited outwards from dy = 0; after a few of a row's tile rows a
  *   wave drops the row when no lane's partial SAD can still beat its best (a partial sum only grows).
  *   The rate then depends on the images: fast when blocks have a clear match near the centre, slower
- *   than the exhaustive search on noise. */
+ *   than the exhaustive search on noise (16x16: up to 1.5x; the 8x8 kernel falls back per wave).
+ * ADAPTIVE (default for 16x16 tiles): PRUNED where it pays.  A small probe kernel in front of the search
+ *   computes the two-row bounds of a sample of every pair's blocks (1.6 % of them) and the search runs a
+ *   pair's block rows pruned when the bounds predict that few candidates survive, exhaustively otherwise
+ *   (the verdicts live in the workspace, aof_ws_layout.hints); for 8x8 tiles the same as PRUNED (that
+ *   kernel decides per wave already). */
 #define AOF_SEARCH_EXHAUSTIVE 0
 #define AOF_SEARCH_PRUNED 1
+#define AOF_SEARCH_ADAPTIVE 2
 int aof_set_search_mode(aof_ctx *ctx, int mode);
+int aof_get_search_mode(const aof_ctx *ctx);
 
 /* ---- the hot path, device-resident (batched) ----
  * d_prev/d_cur: device pointers, pair i at +i*pair_stride bytes, each frame

@@ -251,6 +251,15 @@ def test_c5_1280x960_16x16_search8(aof, orc, synth, gpu_device):
     assert got["blocks"].shape == (2, 4661)
     check_against_oracle(aof, orc, p, prevs, curs, got)
     assert np.array_equal(got["flows"]["flow_x"], shifts[:, 0].astype(np.float32))
+    # (a fresh 16x16 context searches in the adaptive mode; the exhaustive scan on its own as well)
+    assert got["eng"].search_mode == aof.SEARCH_ADAPTIVE
+    import torch
+    eng = aof.FlowEngine(p, 0)
+    eng.set_search_mode(aof.SEARCH_EXHAUSTIVE)
+    blocks, flows, _ = eng.flow_batch(torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device))
+    torch.cuda.synchronize()
+    check_against_oracle(aof, orc, p, prevs, curs, dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows)))
+    eng.close()
 
 
 def test_c4_batch_properties_at_full_size(aof, orc, synth, gpu_device):

@@ -106,7 +106,7 @@ def test_pruned_fuzz(aof, orc, synth, gpu_device, seed):
 def pruned16_matches(aof, orc, p, prevs, curs, device):
     po = orc.params_from(p)
     refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(prevs.shape[0])]
-    for mode in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED):
+    for mode in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED, aof.SEARCH_ADAPTIVE):
         b, f = run(aof, p, prevs, curs, device, mode, hint_fill=0x5A, reps=2)
         for i, r in enumerate(refs):
             assert b[i].tobytes() == r["blocks"].tobytes(), (mode, i)
@@ -170,3 +170,47 @@ def test_pruned16_fuzz(aof, orc, synth, gpu_device, seed):
     if seed % 3 == 0:
         curs[0] = rng.integers(0, 256, curs[0].shape, dtype=np.uint8)
     pruned16_matches(aof, orc, p, prevs, curs, gpu_device)
+
+
+def test_adaptive16_is_the_default_and_judges_every_pair_by_itself(aof, orc, synth, gpu_device):
+    """A fresh 16x16 context runs AOF_SEARCH_ADAPTIVE: a probe kernel in front of the search judges every pair
+    (aof_ws_layout.hints: 1 = few candidates survive the two-row bounds, run the pruned steps; 0 = noise, run
+    the exhaustive scan) and the search follows the verdict per pair.  A batch that mixes clean translations,
+    heavy sensor noise, unrelated frames and a flat pair must come out with BOTH verdicts present, records and
+    flows equal to the oracle's for every pair, and the same bytes as the two fixed modes -- for one and two
+    levels and with the half-pixel step."""
+    import torch
+    W, H = 1280, 960
+    for kw in (dict(), dict(subpixel=1), dict(pyramid_levels=2, mean_subtract=1)):
+        p = aof.default_params(W, H, tile=16, search=8, value_threshold=12000, **kw)
+        reach = 17 if kw.get("pyramid_levels") == 2 else 8
+        clean_p, clean_c, _ = synth.make_batch(W, H, 2, reach, 7100, brightness=9 if kw.get("mean_subtract") else 0)
+        noisy_p, noisy_c, _ = synth.make_batch(W, H, 2, reach, 7200, noise=40)
+        rng = np.random.default_rng(72)
+        unrelated = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        flat = np.full((H, W), 90, np.uint8)
+        prevs = np.stack([clean_p[0], noisy_p[0], clean_p[1], noisy_p[1], clean_p[0], flat])
+        curs = np.stack([clean_c[0], noisy_c[0], clean_c[1], noisy_c[1], unrelated, flat])
+        eng = aof.FlowEngine(p, 0)
+        assert eng.search_mode == aof.SEARCH_ADAPTIVE and eng.variant == "tile16_lds"
+        tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
+        L = aof.workspace_layout(p, 6)
+        ws = torch.full((L.total_bytes,), 0x5A, dtype=torch.uint8, device=gpu_device)
+        blocks, flows, _ = eng.flow_batch(tp, tc, workspace=ws)
+        torch.cuda.synchronize()
+        hints = ws[L.hints:L.hints + 4 * 6].cpu().numpy().view(np.uint32)
+        assert set(hints.tolist()) <= {0, 1}
+        assert hints[0] == 1 and hints[2] == 1, hints          # clean translations: pruning pays
+        assert hints[1] == 0 and hints[3] == 0 and hints[4] == 0, hints   # noise / unrelated frames: it does not
+        got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
+        po = orc.params_from(p)
+        for i in range(6):
+            ref = orc.flow_pair(po, prevs[i], curs[i])
+            assert got["blocks"][i].tobytes() == ref["blocks"].tobytes(), (kw, i)
+            assert got["flows"][i].tobytes() == ref["flow"].tobytes(), (kw, i)
+        for mode in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED):
+            eng.set_search_mode(mode)
+            b2, f2, _ = eng.flow_batch(tp, tc)
+            torch.cuda.synchronize()
+            assert torch.equal(b2, blocks) and torch.equal(f2, flows), (kw, mode)
+        eng.close()
