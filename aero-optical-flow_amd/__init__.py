@@ -60,6 +60,27 @@ class DerotateParams(C.Structure):
 GYRO_DTYPE = np.dtype([("integ_x", "<f4"), ("integ_y", "<f4"), ("integ_z", "<f4"), ("dt_s", "<f4")])
 
 
+class SequenceParams(C.Structure):
+    """``aof_sequence_params`` (include/aof.h)."""
+    _fields_ = [("ingest", IngestParams), ("focal_x", C.c_float), ("focal_y", C.c_float),
+                ("output_rate", C.c_int32), ("offset_timestamp_usec", C.c_uint64),
+                ("system_id", C.c_uint8), ("component_id", C.c_uint8), ("first_seq", C.c_uint8),
+                ("derotate", C.c_uint8), ("derotate_params", DerotateParams)]
+
+
+class SeqLayout(C.Structure):
+    """``aof_seq_layout`` (include/aof.h)."""
+    _fields_ = [(n, C.c_size_t) for n in ("total_bytes", "cropped", "exposure", "flows", "derotated", "count",
+                                          "records", "frames", "frame_len", "scratch")]
+
+
+SEQ_RECORD_DTYPE = np.dtype([("frame", "<u4"), ("quality", "<i4"), ("dt_us", "<i4"), ("flow_x", "<f4"),
+                             ("flow_y", "<f4"), ("gyro_x", "<f4"), ("gyro_y", "<f4"), ("gyro_z", "<f4")])
+SEQ_FRAME_BYTES = 56
+SEQ_STATUS_STALLED = 1
+assert SEQ_RECORD_DTYPE.itemsize == 32
+
+
 class WsLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "sums", "l1_prev", "l1_cur", "l1_blocks", "l1_subdirs", "l1_flows",
@@ -123,6 +144,9 @@ def _load():
         "aof_stream_get_stats": (C.c_int, [VP, P(StreamStats)]),
         "aof_set_vote_deadline_us": (C.c_int, [VP, C.c_uint32]),
         "aof_ingest_batch_device": (C.c_int, [P(IngestParams), VP, I64, I64, VP, I64, VP, VP]),
+        "aof_sequence_layout": (C.c_int, [P(Params), P(SequenceParams), I64, P(SeqLayout)]),
+        "aof_sequence_device": (C.c_int, [VP, P(SequenceParams), VP, I64, I64, VP, VP, VP, C.c_size_t, VP]),
+        "aof_flow_angle": (C.c_float, [C.c_float, C.c_float]),
         "aof_derotate_batch_device": (C.c_int, [P(DerotateParams), VP, VP, I64, VP, VP]),
         "aof_exposure_msv": (C.c_float, [VP]),
         "aof_exposure_bin": (C.c_int, [C.c_int]),
@@ -231,6 +255,33 @@ def derotate_batch(flows, gyro, focal_x, focal_y, max_flow, rate_threshold):
     if rc:
         raise AofError(rc, lib.aof_strerror(rc).decode())
     return out
+
+
+def flow_angle(flow_px: float, focal_px: float) -> float:
+    """Pixel flow -> angular flow (rad): the fixed-operation atan2 of include/aof_math.h."""
+    return float(lib.aof_flow_angle(flow_px, focal_px))
+
+
+def sequence_params(cam_w, cam_h, crop_w, crop_h, focal_x=216.6677, focal_y=216.2457, output_rate=15,
+                    offset_timestamp_usec=0, system_id=1, component_id=100, first_seq=0, derotate=None) -> SequenceParams:
+    """``aof_sequence_params``; derotate: None or (max_flow, rate_threshold) of the gyro compensation."""
+    sp = SequenceParams()
+    sp.ingest = IngestParams(cam_w, cam_h, crop_w, crop_h)
+    sp.focal_x, sp.focal_y, sp.output_rate = focal_x, focal_y, output_rate
+    sp.offset_timestamp_usec = offset_timestamp_usec
+    sp.system_id, sp.component_id, sp.first_seq = system_id, component_id, first_seq & 0xFF
+    sp.derotate = 0 if derotate is None else 1
+    if derotate is not None:
+        sp.derotate_params = DerotateParams(focal_x, focal_y, derotate[0], derotate[1])
+    return sp
+
+
+def sequence_layout(p: Params, sp: SequenceParams, n_frames: int) -> SeqLayout:
+    L = SeqLayout()
+    rc = lib.aof_sequence_layout(C.byref(p), C.byref(sp), n_frames, C.byref(L))
+    if rc:
+        raise AofError(rc, lib.aof_strerror(rc).decode())
+    return L
 
 
 def exposure_msv(hist) -> float:
@@ -384,6 +435,43 @@ class FlowEngine:
                     self._check(rc)
         enqueue.keep = keep
         return enqueue
+
+    # -- a recorded frame sequence as one device pipeline -------------------------------
+    def sequence(self, sp: SequenceParams, camera, time_us, gyro=None, workspace=None):
+        """aof_sequence_device: camera uint8 CUDA tensor [n, cam_h, cam_w]; time_us int64 CUDA tensor [n]
+        (microseconds relative to the first frame); gyro float32 CUDA tensor [n, 4] (integ_x, integ_y,
+        integ_z, dt_s of the interval that ends at frame k) or None.  Everything is enqueued on torch's
+        current stream.  Returns (workspace, layout): read the outputs with sequence_outputs()."""
+        import torch
+        n = camera.shape[0]
+        L = sequence_layout(self.params, sp, n)
+        if workspace is None:
+            workspace = torch.empty(L.total_bytes, dtype=torch.uint8, device=camera.device)
+        assert time_us.dtype == torch.int64 and time_us.numel() == n
+        stream = torch.cuda.current_stream(camera.device).cuda_stream
+        self._check(lib.aof_sequence_device(self._ctx, C.byref(sp), camera.data_ptr(), camera.stride(0) if n else 0, n,
+                                            time_us.data_ptr(), gyro.data_ptr() if gyro is not None else None,
+                                            workspace.data_ptr(), workspace.numel(), stream))
+        return workspace, L
+
+    def sequence_outputs(self, sp: SequenceParams, workspace, L: SeqLayout, n: int):
+        """Host views of what a (completed) sequence() call left in its workspace."""
+        p = self.params
+        ws = workspace.cpu().numpy()
+        pairs = max(n - 1, 0)
+        count = ws[L.count:L.count + 16].view(np.uint32)
+        out = {
+            "records": ws[L.records:L.records + 32 * int(count[0])].view(SEQ_RECORD_DTYPE),
+            "frames_sent": int(count[1]), "status": int(count[2]),
+            "cropped": ws[L.cropped:L.cropped + n * p.width * p.height].reshape(n, p.height, p.width),
+            "exposure": ws[L.exposure:L.exposure + 40 * n].view(np.uint32).reshape(n, 10),
+            "flows": ws[L.flows:L.flows + 16 * pairs].view(FLOW_DTYPE),
+            "derotated": ws[L.derotated:L.derotated + 8 * pairs].view(np.float32).reshape(pairs, 2) if sp.derotate else None,
+        }
+        lens = ws[L.frame_len:L.frame_len + int(count[0])]
+        out["mavlink"] = [bytes(ws[L.frames + SEQ_FRAME_BYTES * m:L.frames + SEQ_FRAME_BYTES * m + int(lens[m])])
+                          for m in range(int(count[0]))]
+        return out
 
     # -- host buffers -----------------------------------------------------------
     def flow_pair_host(self, prev: np.ndarray, cur: np.ndarray):

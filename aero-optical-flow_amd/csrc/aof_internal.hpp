@@ -197,6 +197,34 @@ inline unsigned long long resident_word(uint32_t request, int slot, uint32_t pre
 int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_record, const uint8_t *frame_a,
                          const uint8_t *frame_b, uint32_t served, uint32_t launch_no, uint64_t idle_ticks,
                          uint64_t life_ticks, void *stream);
+// The output side of a frame sequence (k_sequence.hip): rate limiter, gyro sums, angles, OPTICAL_FLOW_RAD frames.
+constexpr int64_t kLimitScanFrames = 4096;   // a publication must come within this many frames of the previous one
+struct SequenceArgs {
+    int64_t n_frames;
+    const uint64_t *time_us;       // [n_frames] frame times relative to the first frame (mainloop.cpp:305-311)
+    const aof_gyro *gyro;          // [n_frames] gyro integrated over the interval that ends at frame k, or nullptr
+    const aof_flow *flows;         // [n_frames - 1]: pair k = frames k, k + 1
+    int32_t output_rate;
+    float period_us;               // 1e6f / output_rate, divided on the host as the facade divides
+    float focal_x, focal_y;
+    uint64_t offset_timestamp_usec;
+    uint8_t system_id, component_id, first_seq;
+    uint32_t *jump[2], *hops[2];   // [n_frames + 1] each: pointer doubling, ping-pong
+    uint8_t *reached;              // [n_frames + 1]: 0, or the round in which the node was marked + 1
+    uint32_t *rank;                // [n_frames + 1]: position of a marked node on the chain = its message index
+    uint32_t *count;               // [2]: records written, frames sent
+    uint32_t *status;              // [1]: AOF_SEQ_STATUS_* flags (zeroed by the caller of the launcher)
+    aof_seq_record *records;       // [n_frames]
+    uint8_t *frames;               // [n_frames][AOF_SEQ_FRAME_BYTES], message m at + 56 m; or nullptr
+    uint8_t *frame_len;            // [n_frames]
+};
+inline int sequence_rounds(int64_t n_frames)   // smallest R with 2^R > n_frames (the chain has at most that many hops)
+{
+    int r = 0;
+    while ((1ll << r) <= n_frames) r++;
+    return r;
+}
+int launch_sequence_output(const SequenceArgs &a, void *stream);
 int launch_reduce(const ReduceArgs &a, void *stream);
 int launch_derotate(const aof_derotate_params &p, const aof_flow *flows, const aof_gyro *gyro,
                     int64_t n, float *out, void *stream);

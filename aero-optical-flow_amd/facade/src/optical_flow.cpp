@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "aof.h"
+#include "aof_math.h"
 #include "flow_opencv.hpp"
 #include "flow_px4.hpp"
 
@@ -176,8 +177,10 @@ int OpticalFlow::integrate(const uint8_t *img, uint32_t img_time_us, int &dt_us,
 	if (first) return 0;  // nothing to compare the very first frame with
 	flow_quality = limitRate(flow_quality, img_time_us, &dt_us, &px, &py);
 	if (flow_quality < 0) return flow_quality;
-	flow_x = std::atan2(px, focal_length_x);  // pixel flow -> angular flow (rad)
-	flow_y = std::atan2(py, focal_length_y);
+	// pixel flow -> angular flow (rad): atan2 as a fixed sequence of IEEE operations (include/aof_math.h), the
+	// same bits the device pipeline (aof_sequence_device) produces
+	flow_x = aof_atan2f(px, focal_length_x);
+	flow_y = aof_atan2f(py, focal_length_y);
 	return flow_quality;
 }
 

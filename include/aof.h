@@ -281,6 +281,71 @@ typedef struct aof_derotate_params {
 int aof_derotate_batch_device(const aof_derotate_params *p, const aof_flow *d_flows,
                               const aof_gyro *d_gyro, int64_t n, float *d_out, void *stream);
 
+/* ---- a recorded frame SEQUENCE as one device pipeline (the reference's per-frame loop,
+ * /root/reference/src/mainloop.cpp:295-373, for all frames of a recording at once) ----
+ * n sensor frames, their time stamps and the gyro integrated between them, all resident in device memory, go
+ * through, in ONE call that only enqueues (no allocation, no host synchronisation: it can be captured):
+ *   1. ingest: centre crop + exposure histogram per frame (aof_ingest_batch_device; mainloop.cpp:295-298,203-214)
+ *   2. flow in sequence mode: frame k is `cur` of pair k-1 and `prev` of pair k (aof_flow_batch_device)
+ *   3. the rate limiter of calcFlow (flows of frames with quality > 0 summed until
+ *      (float)(t - t_last) > 1e6f / output_rate, u32 wrap-around arithmetic; mainloop.cpp:322-331)
+ *   4. gyro de-rotation of every pair's pixel flow (aof_derotate_batch_device; an extra output: the message
+ *      itself carries the flow and the gyro side by side, as the reference sends them)
+ *   5. pixel flow -> angular flow (aof_flow_angle), the OPTICAL_FLOW_RAD field mapping (mainloop.cpp:359-371)
+ *      and the MAVLink 2 frame (mavlink_tcp.cpp:142-162) of every published flow.
+ * The records and frames are byte-identical to driving the C++ facade frame by frame over the same frames
+ * (OpticalFlowOpenCV::calcFlow + fillOpticalFlowRad + packOpticalFlowRad): the float operations are the
+ * host's, in the host's order.  The context's parameters must describe the CROPPED frame. */
+typedef struct aof_sequence_params {
+    aof_ingest_params ingest;        /* sensor frame -> crop; crop size == the context's frame size */
+    float focal_x, focal_y;          /* px (main.cpp:60-61) */
+    int32_t output_rate;             /* Hz (main.cpp:59); <= 0 publishes every frame */
+    uint64_t offset_timestamp_usec;  /* vehicle time of the first frame (mainloop.cpp:360); 0 = not known yet:
+                                        records are written, no frame is sent (mainloop.cpp:353-357) */
+    uint8_t system_id, component_id; /* MAVLink ids (mavlink_tcp.h:66-67: 1, MAV_COMP_ID_CAMERA = 100) */
+    uint8_t first_seq;               /* MAVLink sequence number of the first frame sent */
+    uint8_t derotate;                /* 1: also write the de-rotated pixel flow of every pair */
+    aof_derotate_params derotate_params;
+} aof_sequence_params;
+
+/* What calcFlow returned for a frame it published (quality >= 0), plus the gyro taken with it. */
+typedef struct aof_seq_record {
+    uint32_t frame;          /* index of the frame */
+    int32_t quality;         /* 0..255 */
+    int32_t dt_us;           /* integration time */
+    float flow_x, flow_y;    /* rad */
+    float gyro_x, gyro_y, gyro_z; /* rad, integrated since the previous record (before the axis switch) */
+} aof_seq_record;
+
+#define AOF_SEQ_FRAME_BYTES 56     /* room per MAVLink 2 frame: 10 + 44 + 2 */
+#define AOF_SEQ_STATUS_STALLED 1u  /* more than 4096 frames in a row without reaching the output period: the
+                                      time stamps do not advance; nothing is published behind that point */
+
+/* Byte offsets of the pipeline's outputs and intermediates inside the caller's workspace. */
+typedef struct aof_seq_layout {
+    size_t total_bytes;
+    size_t cropped;    /* u8 [n][crop_h][crop_w]: the frame sequence the flow runs on */
+    size_t exposure;   /* u32 [n][10]: exposure histograms */
+    size_t flows;      /* aof_flow [n-1]: pair k = frames k, k+1 */
+    size_t derotated;  /* float [n-1][2] (params.derotate) */
+    size_t count;      /* u32 [4]: records written, frames sent, AOF_SEQ_STATUS_* flags, 0 */
+    size_t records;    /* aof_seq_record [n], the first count[0] valid, in frame order */
+    size_t frames;     /* u8 [n][AOF_SEQ_FRAME_BYTES]: frame of record m at + 56 m */
+    size_t frame_len;  /* u8 [n]: length of frame m (0: not sent) */
+    size_t scratch;    /* limiter state and the flow engine's workspace */
+} aof_seq_layout;
+int aof_sequence_layout(const aof_params *p, const aof_sequence_params *sp, int64_t n_frames, aof_seq_layout *out);
+/* d_camera: frame i at + i*camera_stride.  d_time_us: [n] frame times in microseconds relative to the first
+ * frame (mainloop.cpp:305-311; calcFlow sees them truncated to 32 bits).  d_gyro: [n], entry k = gyro integrated
+ * over the interval that ends at frame k (dt_s: that interval, for the de-rotation), or NULL (zeros).
+ * d_workspace: >= aof_sequence_layout().total_bytes, 256-byte aligned. */
+int aof_sequence_device(aof_ctx *ctx, const aof_sequence_params *sp, const uint8_t *d_camera, int64_t camera_stride,
+                        int64_t n_frames, const uint64_t *d_time_us, const aof_gyro *d_gyro, void *d_workspace,
+                        size_t workspace_bytes, void *stream);
+/* Pixel flow -> angular flow (rad) exactly as the facade and the device pipeline compute it:
+ * atan2(flow_px, focal_px) as a fixed sequence of IEEE double operations (include/aof_math.h).  Host only. */
+float aof_flow_angle(float flow_px, float focal_px);
+
 /* ---- measurement ----
  * With profiling on, every launch is bracketed by HIP events on the stream it
  * is launched on; the last AOF_PROFILE_RING launches of each kernel are kept.

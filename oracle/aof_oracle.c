@@ -545,6 +545,41 @@ void orc_derotate(float flow_x, float flow_y, float gx, float gy, float dt_s, fl
  * keep the previous frame, return a negative value until 1/output_rate has
  * elapsed, then hand out the flow integrated over that period as an angle
  * (rad) together with dt_us and a 0..255 quality. */
+/* Pixel flow -> angular flow.  DESIGN.md "Facade semantics": atan2(flow_px, focal_px) evaluated as a FIXED
+ * sequence of IEEE double operations (so that host and device agree to the bit; libm's atan2f is not
+ * specified to the last bit): t = min(|x|,|y|) / max(|x|,|y|); above tan(pi/8) the argument is folded by
+ * atan(t) = pi/4 + atan((t-1)/(t+1)); atan(u) = u (1 - z/3 + z^2/5 - ... + z^14/29), z = u^2, Horner from
+ * the last term with every product and every difference rounded on its own (no fused multiply-add);
+ * quadrant by the signs; rounded to float once at the end.  The oracle's own restatement of that spec. */
+#if defined(__GNUC__) && !defined(__clang__)
+__attribute__((optimize("fp-contract=off")))
+#endif
+float orc_angle(float flow_px, float focal_px)
+{
+    const double PI = 3.14159265358979323846;
+    double y = flow_px, x = focal_px;
+    if (isnan(x) || isnan(y)) return flow_px + focal_px;
+    double ax = fabs(x), ay = fabs(y);
+    double small = ax < ay ? ax : ay, large = ax < ay ? ay : ax;
+    double t = large == 0.0 ? 0.0 : (small == large ? 1.0 : small / large);
+    double fold = 0.0, u = t;
+    if (t > 0.41421356237309504880) {
+        u = (t - 1.0) / (t + 1.0);
+        fold = PI / 4.0;
+    }
+    double z = u * u, series = 1.0 / 29.0;
+    for (int odd = 27; odd >= 1; odd -= 2) {
+        double prod = series * z;
+        series = 1.0 / (double)odd - prod;
+    }
+    double prod = u * series;
+    double angle = fold + prod;
+    if (ay > ax) angle = PI / 2.0 - angle;
+    if (signbit(x)) angle = PI - angle;
+    if (signbit(y)) angle = -angle;
+    return (float)angle;
+}
+
 static void limit_rate_reset(orc_px4 *s)
 {
     s->sum_flow_x = s->sum_flow_y = 0.0f;
@@ -611,7 +646,7 @@ int orc_px4_calc_flow(orc_px4 *s, const uint8_t *img, uint32_t t_us, int *dt_us,
             return -1; /* still integrating */
         }
     }
-    *flow_x = atan2f(fx, s->focal_x);
-    *flow_y = atan2f(fy, s->focal_y);
+    *flow_x = orc_angle(fx, s->focal_x);
+    *flow_y = orc_angle(fy, s->focal_y);
     return q;
 }

@@ -136,6 +136,9 @@ void orc_derotate(float flow_x, float flow_y, float gx, float gy, float dt_s, fl
 
 /* --- facade semantics (calcFlow: previous-frame keeping, rate limiting,
  *     pixel->angle conversion), mainloop.cpp:322-331,359-363 ---------------- */
+/* Pixel flow -> angular flow (rad): the spec's fixed-operation atan2 (DESIGN.md "Facade semantics"). */
+float orc_angle(float flow_px, float focal_px);
+
 typedef struct orc_px4 {
     orc_params params;
     float focal_x, focal_y;

@@ -70,6 +70,8 @@ def _load():
     lib.orc_exposure_msv.restype = C.c_float
     lib.orc_exposure_msv.argtypes = [VP]
     lib.orc_derotate.argtypes = [C.c_float] * 9 + [P(C.c_float), P(C.c_float)]
+    lib.orc_angle.restype = C.c_float
+    lib.orc_angle.argtypes = [C.c_float, C.c_float]
     lib.orc_px4_init.argtypes = [P(Px4State), P(Params), C.c_float, C.c_float, C.c_int]
     lib.orc_px4_free.argtypes = [P(Px4State)]
     lib.orc_px4_calc_flow.argtypes = [P(Px4State), VP, C.c_uint32, P(C.c_int), P(C.c_float),
@@ -160,6 +162,11 @@ def flow_batch(p: Params, prevs, curs, threads=0):
 def set_fast_sad(on):
     """bench.py's cpu_baseline leg only: SAD through the host's SAD instruction (SSE2 psadbw)."""
     lib.orc_set_fast_sad(int(bool(on)))
+
+
+def angle(flow_px, focal_px):
+    """Pixel flow -> angular flow (rad): the oracle's restatement of the spec's fixed-operation atan2."""
+    return float(lib.orc_angle(flow_px, focal_px))
 
 
 def fast_sad_available():
