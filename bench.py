@@ -300,6 +300,101 @@ def bench_ingest(args, aof, device, rank, world, dist):
         dist.destroy_process_group()
 
 
+def bench_sequence(args, aof, device, rank, world, dist):
+    """The reference's whole per-frame loop (mainloop.cpp:295-373) over a recorded sequence as ONE device
+    pipeline (aof_sequence_device): --pairs * 64 sensor frames of 320x240 (main.cpp:54-55 defaults) -> 128x128
+    crop -> OpticalFlowOpenCV's configuration (two levels + mean equalisation) -> rate limiter at 15 Hz ->
+    de-rotation -> OPTICAL_FLOW_RAD frames.  Step = one call over the resident sequence."""
+    import importlib
+    synth = importlib.import_module(ge.PKG_NAME + ".synth")
+    cam_w, cam_h, crop = 320, 240, 128
+    n = args.pairs * 64
+    base, _ = synth.make_sequence(cam_w, cam_h, 96, 6, seed=9 + rank, max_step=4)
+    cam = torch.from_numpy(base).to(device)[torch.arange(n, device=device) % 96].contiguous()
+    g = torch.Generator(device=device)
+    g.manual_seed(12 + rank)
+    times = torch.cumsum(torch.randint(12500, 14200, (n,), generator=g, device=device, dtype=torch.int64), 0)
+    times = times - times[0]
+    gyro = torch.randn((n, 4), generator=g, device=device, dtype=torch.float32) * 0.003
+    gyro[:, 3] = 0.0133
+    p = aof.px4flow_params(crop, crop, pyramid_levels=2, mean_subtract=1)
+    eng = aof.FlowEngine(p, device.index or 0)
+    sp = aof.sequence_params(cam_w, cam_h, crop, crop, 216.6677, 216.2457, 15, 5_000_000, 1, 100, 0, derotate=(9.5, 0.01))
+    ws, L = eng.sequence(sp, cam, times, gyro)
+    for _ in range(max(args.warmup, 3)):
+        eng.sequence(sp, cam, times, gyro, workspace=ws)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.sequence(sp, cam, times, gyro, workspace=ws)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out = eng.sequence_outputs(sp, ws, L, n)
+    step_ms = elapsed / args.steps * 1e3
+    # compulsory bytes per frame: the crop region of the sensor frame read once, the cropped frame written once
+    # and read twice by the flow (it is cur of one pair and prev of the next), 16 B flow record, ~56 B of frame
+    # per publication
+    alg = crop * crop * 4 + 40 + 16 + 8
+    achieved = alg * n / (step_ms * 1e-3) / 1e9
+    line = {"metric": "sensor frames/s through the whole per-frame loop on the device (320x240 -> 128x128 crop, 8x8 SAD +-4 on two "
+                      "levels, 15 Hz rate limiter, de-rotation, OPTICAL_FLOW_RAD frames)",
+            "value": round(world * n * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 3), "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "seq: aof_sequence_device over a resident recording", "frames_per_gpu": n,
+                       "records_published": int(len(out["records"])), "frames_sent": out["frames_sent"],
+                       "limiter_rounds": int(np.ceil(np.log2(n + 1)))},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "whole pipeline (all kernels of one call)",
+                         "kernel_ms": round(step_ms, 5), "algorithmic_bytes_per_frame": alg, "frames_per_launch": n}}
+    if rank == 0:
+        from oracle import pyoracle as orc
+        # parity on a prefix: the oracle's calcFlow chain over the same cropped frames
+        m = min(n, 600)
+        o = orc.Px4(orc.params_from(p), 216.6677, 216.2457, 15)
+        cropped = out["cropped"][:m]
+        th = times[:m].cpu().numpy()
+        ok, k_rec = True, 0
+        for k in range(m):
+            q, dt, ax, ay = o.calc_flow(cropped[k], int(th[k]))
+            if q < 0:
+                continue
+            r = out["records"][k_rec]
+            ok &= (int(r["frame"]), int(r["quality"]), int(r["dt_us"])) == (k, q, dt)
+            ok &= np.float32(ax).tobytes() == r["flow_x"].tobytes() and np.float32(ay).tobytes() == r["flow_y"].tobytes()
+            k_rec += 1
+        line["parity"] = {"oracle_records_bit_exact": bool(ok), "frames_checked": m, "records_checked": k_rec,
+                          "note": "oracle = this repo's CPU restatement (upstream PX4 source unavailable)"}
+        if world == 1 and args.cpu_seconds > 0:
+            o2 = orc.Px4(orc.params_from(p), 216.6677, 216.2457, 15)
+            simd = orc.fast_sad_available()
+            orc.set_fast_sad(simd)
+            t1 = time.perf_counter()
+            done = 0
+            try:
+                while time.perf_counter() - t1 < min(args.cpu_seconds, 10.0):
+                    o2.calc_flow(cropped[done % m], int(th[done % m]))
+                    done += 1
+            finally:
+                orc.set_fast_sad(False)
+            spent = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": round(done / spent, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+                                    "sample": f"{done} calcFlow calls of the oracle on the cropped frames (crop, limiter and angle "
+                                              f"included; SAD via {'SSE2 psadbw' if simd else 'the byte loop'}), {spent:.1f} s"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def pmc_traffic(key, field="hbm_bytes_per_launch"):
     """HBM bytes per launch from the committed PMC summary of the same command (profiles/), and its source.
     field "step_bytes": all kernels of one step instead of the dominant kernel alone."""
@@ -367,7 +462,7 @@ def main():
     ap.add_argument("--settle-steps", type=int, default=500,
                     help="untimed steps before the warm-up steps (clock settling under sustained load); 0 = off")
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1", "derotate"])
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1", "derotate", "seq"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
     ap.add_argument("--search", default="auto", choices=["auto", "exhaustive", "pruned", "adaptive"],
                     help="auto (default): what a fresh context runs -- exhaustive for 8x8 tiles (the data-independent "
@@ -463,6 +558,8 @@ def main():
         return bench_c1(args, aof, rank, world, dist)
     if args.workload == "derotate":
         return bench_derotate(args, aof, device, rank, world, dist)
+    if args.workload == "seq":
+        return bench_sequence(args, aof, device, rank, world, dist)
     desc, W, H, over, reach = WORKLOADS[args.workload]
     if args.max_shift is not None:
         reach = args.max_shift
