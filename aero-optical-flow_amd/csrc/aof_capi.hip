@@ -377,6 +377,19 @@ int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, h
     a.l1_prev = two ? v.l1_prev + first * l1_frame : nullptr;
     a.l1_cur = two ? v.l1_cur + first * l1_frame : nullptr;
     a.sums = sums; a.n_pairs = n;
+    // A frame sequence (aof.h: d_cur = d_prev + one frame, pair_stride = one frame): frame k is cur of pair k-1
+    // and prev of pair k -- K1 sums and filters every frame once instead of twice.  The level-1 frames then
+    // form a sequence of their own (n + 1 frames from the start of the workspace's two level-1 regions, which
+    // are adjacent: 2 n frames of room), which the level-1 search views twice the same way.
+    const bool sequence = v.cur == v.prev + (int64_t)p.width * p.height && v.stride == (int64_t)p.width * p.height &&
+                          first == 0 && v.l1_cur >= v.l1_prev;
+    if (sequence) {
+        a.sequence = 1;
+        a.n_pairs = n + 1;
+        a.cur = nullptr; a.l1_cur = nullptr;
+    } else {
+        a.sequence = 0;
+    }
     {
         Timed t(ctx, AOF_K_PYRAMID, s);
         const int rc = launch_pyramid(a, s);
@@ -384,7 +397,7 @@ int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, h
     }
     if (!two) return 0;
     const int64_t nb1 = ctx->g1.blocks();
-    SearchArgs sa = search_args(ctx, 1, a.l1_prev, a.l1_cur, l1_frame, v.blocks1 + first * nb1,
+    SearchArgs sa = search_args(ctx, 1, a.l1_prev, sequence ? a.l1_prev + l1_frame : a.l1_cur, l1_frame, v.blocks1 + first * nb1,
                                 v.subdirs1 ? v.subdirs1 + first * nb1 : nullptr, nullptr, sums, n);
     sa.hints = v.hints ? v.hints + first : nullptr;
     return enqueue_level(ctx, 1, sa, flow_tail(ctx, 1, v.flows1 + first, nullptr),

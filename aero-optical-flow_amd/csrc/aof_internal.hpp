@@ -136,6 +136,10 @@ struct PyramidArgs {
     uint8_t *l1_prev, *l1_cur; // [n_pairs][h/2][w/2] or nullptr (sums only)
     uint32_t *sums;            // [n_pairs][2][2] or nullptr (pyramid only)
     int64_t n_pairs;
+    // A frame SEQUENCE (cur = prev + one frame, pair_stride = one frame): every frame is summed and filtered ONCE.
+    // n_pairs then counts the FRAMES (pairs + 1), `prev` is the first frame, `cur` / `l1_cur` are not used,
+    // l1_prev receives one level-1 frame per frame, and frame f's sums go to pair f (prev) and pair f - 1 (cur).
+    int32_t sequence;
 };
 
 // Kernel launchers (one per .hip file).  All enqueue on `stream` and return the

@@ -16,6 +16,25 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kItemsPerBlock = 1024;  // 16-px x 2-row items per workgroup
 
+// One wave's share of a frame's byte sums into the pairs' records [pair][prev, cur][level 0, level 1].  In a
+// sequence frame f is prev of pair f and cur of pair f - 1: both records get it (a.n_pairs counts FRAMES then).
+__device__ __forceinline__ void publish_sums(const PyramidArgs &a, int64_t unit, int frame, uint32_t sum0, uint32_t sum1)
+{
+    if (!a.sequence) {
+        atomicAdd(&a.sums[unit * 4 + frame * 2 + 0], sum0);
+        atomicAdd(&a.sums[unit * 4 + frame * 2 + 1], sum1);
+        return;
+    }
+    if (unit < a.n_pairs - 1) {
+        atomicAdd(&a.sums[unit * 4 + 0], sum0);
+        atomicAdd(&a.sums[unit * 4 + 1], sum1);
+    }
+    if (unit > 0) {
+        atomicAdd(&a.sums[(unit - 1) * 4 + 2], sum0);
+        atomicAdd(&a.sums[(unit - 1) * 4 + 3], sum1);
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_pyramid_vec(PyramidArgs a, int rows_per_strip,
                                                           int nstrips)
 {
@@ -24,8 +43,10 @@ __global__ __launch_bounds__(kThreads) void k_pyramid_vec(PyramidArgs a, int row
     uint32_t id = blockIdx.x;
     const int strip = (int)(id % (uint32_t)nstrips);
     id /= (uint32_t)nstrips;
-    const int frame = (int)(id & 1u);
-    const int64_t pair = (int64_t)(id >> 1);
+    // a frame SEQUENCE (a.sequence): unit `id` is FRAME id -- prev of pair id and cur of pair id - 1 --, summed
+    // and filtered once; otherwise frame (id & 1) of pair (id >> 1)
+    const int frame = a.sequence ? 0 : (int)(id & 1u);
+    const int64_t pair = a.sequence ? (int64_t)id : (int64_t)(id >> 1);
     const uint8_t *src = (frame ? a.cur : a.prev) + pair * a.pair_stride;
     uint8_t *dst = nullptr;
     if (a.l1_prev) dst = (frame ? a.l1_cur : a.l1_prev) + pair * (int64_t)w1 * h1;
@@ -58,10 +79,7 @@ __global__ __launch_bounds__(kThreads) void k_pyramid_vec(PyramidArgs a, int row
     if (a.sums) {
         sum0 = wave_sum_u32(sum0);
         sum1 = wave_sum_u32(sum1);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&a.sums[pair * 4 + frame * 2 + 0], sum0);
-            atomicAdd(&a.sums[pair * 4 + frame * 2 + 1], sum1);
-        }
+        if ((threadIdx.x & 63) == 0) publish_sums(a, pair, frame, sum0, sum1);
     }
 }
 
@@ -73,8 +91,8 @@ __global__ __launch_bounds__(kThreads) void k_pyramid_scalar(PyramidArgs a, int 
     uint32_t id = blockIdx.x;
     const int strip = (int)(id % (uint32_t)nstrips);
     id /= (uint32_t)nstrips;
-    const int frame = (int)(id & 1u);
-    const int64_t pair = (int64_t)(id >> 1);
+    const int frame = a.sequence ? 0 : (int)(id & 1u);
+    const int64_t pair = a.sequence ? (int64_t)id : (int64_t)(id >> 1);
     const uint8_t *src = (frame ? a.cur : a.prev) + pair * a.pair_stride;
     uint8_t *dst = nullptr;
     if (a.l1_prev) dst = (frame ? a.l1_cur : a.l1_prev) + pair * (int64_t)w1 * h1;
@@ -99,10 +117,7 @@ __global__ __launch_bounds__(kThreads) void k_pyramid_scalar(PyramidArgs a, int 
     if (a.sums) {
         sum0 = wave_sum_u32(sum0);
         sum1 = wave_sum_u32(sum1);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&a.sums[pair * 4 + frame * 2 + 0], sum0);
-            atomicAdd(&a.sums[pair * 4 + frame * 2 + 1], sum1);
-        }
+        if ((threadIdx.x & 63) == 0) publish_sums(a, pair, frame, sum0, sum1);
     }
 }
 
@@ -131,19 +146,21 @@ int launch_pyramid(const PyramidArgs &a, void *stream)
 {
     if (a.n_pairs == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // (a.sequence: n_pairs counts the FRAMES of the sequence, one unit each; n_pairs - 1 pairs of sums)
+    const int64_t units = a.sequence ? a.n_pairs : a.n_pairs * 2;
     if (a.sums) {
-        const int rc = launch_zero_words(a.sums, a.n_pairs * 4, stream);
+        const int rc = launch_zero_words(a.sums, (a.sequence ? a.n_pairs - 1 : a.n_pairs) * 4, stream);
         if (rc) return rc;
     }
     const bool vec = (a.w % 16 == 0) && (a.h % 2 == 0) && (a.pair_stride % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(a.prev) % 16 == 0) &&
-                     (reinterpret_cast<uintptr_t>(a.cur) % 16 == 0);
+                     (a.sequence || reinterpret_cast<uintptr_t>(a.cur) % 16 == 0);
     if (vec) {
         const int chunks = a.w / 16, h1 = a.h / 2;
         int rows = kItemsPerBlock / chunks;
         if (rows < 1) rows = 1;
         const int nstrips = (h1 + rows - 1) / rows;
-        const int64_t total = a.n_pairs * 2 * nstrips;
+        const int64_t total = units * nstrips;
         if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(k_pyramid_vec, dim3((uint32_t)total), dim3(kThreads), 0, s, a, rows,
                            nstrips);
@@ -151,7 +168,7 @@ int launch_pyramid(const PyramidArgs &a, void *stream)
         const int64_t cells = (int64_t)((a.w + 1) / 2) * ((a.h + 1) / 2);
         int nstrips = (int)((cells + kItemsPerBlock - 1) / kItemsPerBlock);
         if (nstrips < 1) nstrips = 1;
-        const int64_t total = a.n_pairs * 2 * nstrips;
+        const int64_t total = units * nstrips;
         if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(k_pyramid_scalar, dim3((uint32_t)total), dim3(kThreads), 0, s, a,
                            nstrips);

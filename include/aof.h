@@ -147,7 +147,10 @@ int aof_get_search_mode(const aof_ctx *ctx);
 /* ---- the hot path, device-resident (batched) ----
  * d_prev/d_cur: device pointers, pair i at +i*pair_stride bytes, each frame
  * width*height bytes.  For a frame SEQUENCE pass d_cur = d_prev + width*height
- * and pair_stride = width*height.
+ * and pair_stride = width*height: frame k is cur of pair k-1 and prev of pair k, and
+ * the passes that work per frame (pixel sums, 2x2 pyramid) then run once per FRAME
+ * (the workspace's level-1 frames, where the separate kernels write them, are then
+ * n_pairs + 1 consecutive frames from offset l1_prev on).
  * d_blocks: [n_pairs][nb0] records (4-byte aligned) or NULL.  d_subdirs: [n_pairs][nb0] or NULL.
  * d_flows: [n_pairs], required.  d_workspace: >= aof_workspace_layout().total_bytes,
  * 256-byte aligned.  stream: hipStream_t (NULL = default stream).

@@ -870,6 +870,52 @@ def test_frame_sequence_via_pair_stride(aof, orc, synth, gpu_device):
     assert np.array_equal(got["flows"]["flow_x"], steps[:, 0].astype(np.float32))
 
 
+@pytest.mark.parametrize("kw,size,n", [
+    (dict(pyramid_levels=2, mean_subtract=1, _px4=1), (128, 128), 200),    # the sequence pipeline's own configuration
+    (dict(pyramid_levels=2, mean_subtract=1), (160, 128), 40),             # dense grid: fused coarse kernel / split K1
+    (dict(mean_subtract=1), (136, 72), 30),                                # one level, sums only, scalar K1 (width % 16 != 0)
+    (dict(pyramid_levels=2, _px4=1), (96, 80), 2),                         # a single pair of a sequence view
+    (dict(tile=16, search=8, pyramid_levels=2, mean_subtract=1, value_threshold=12000), (320, 256), 12),
+])
+def test_frame_sequence_sums_and_filters_every_frame_once(aof, orc, synth, gpu_device, kw, size, n):
+    """In the sequence view (d_cur = d_prev + one frame, pair_stride = one frame) K1 runs once per FRAME: frame
+    k's sums land in pair k (prev) and pair k-1 (cur), its level-1 image once in the workspace, and the level-1
+    search views that sequence twice.  Records, flows, pixel sums and level-1 frames against the oracle and
+    against the same pairs run as independent copies."""
+    import torch
+    kw = dict(kw)
+    W, H = size
+    px4 = kw.pop("_px4", 0)
+    p = aof.px4flow_params(W, H, **kw) if px4 else aof.default_params(W, H, **kw)
+    frames, _ = synth.make_sequence(W, H, n + 1, 6, seed=41, max_step=5)
+    frames = frames.copy()
+    frames[1::3] = np.clip(frames[1::3].astype(np.int16) + 11, 0, 255).astype(np.uint8)   # exposure steps: deltas at work
+    t = torch.from_numpy(frames).to(gpu_device)
+    L = aof.workspace_layout(p, n)
+    for split in (False, True):
+        eng = aof.FlowEngine(p, 0)
+        if split:
+            eng.set_split_coarse(True)
+        ws = torch.full((L.total_bytes,), 0xA5, dtype=torch.uint8, device=gpu_device)
+        blocks, flows, _ = eng.flow_batch(t[:-1], t[1:], n_pairs=n, pair_stride=W * H, workspace=ws)
+        # the same pairs as independent copies (no sequence view: cur is another buffer)
+        prev_c, cur_c = t[:-1].clone(), t[1:].clone()
+        b2, f2, ws2 = eng.flow_batch(prev_c, cur_c)
+        torch.cuda.synchronize()
+        assert torch.equal(blocks, b2) and torch.equal(flows, f2), split
+        got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
+        sample = sorted(set([0, 1, n // 2, n - 1]))
+        check_against_oracle(aof, orc, p, frames[:-1][sample], frames[1:][sample],
+                             dict(blocks=got["blocks"][sample], flows=got["flows"][sample]))
+        if p.mean_subtract and (split or px4 or p.tile == 16 or p.pyramid_levels == 1):   # (K1 ran: its sums are in the workspace)
+            sums = ws[L.sums:L.sums + 16 * n].cpu().numpy().view(np.uint32).reshape(n, 2, 2)
+            sums2 = ws2[L.sums:L.sums + 16 * n].cpu().numpy().view(np.uint32).reshape(n, 2, 2)
+            assert np.array_equal(sums, sums2)
+            assert np.array_equal(sums[:, 0, 0], frames[:-1].reshape(n, -1).sum(axis=1, dtype=np.uint64).astype(np.uint32))
+            assert np.array_equal(sums[:, 1, 0], frames[1:].reshape(n, -1).sum(axis=1, dtype=np.uint64).astype(np.uint32))
+        eng.close()
+
+
 def test_padded_pair_stride_and_caller_buffers(aof, orc, synth, gpu_device):
     import torch
     p = aof.default_params(128, 96)
