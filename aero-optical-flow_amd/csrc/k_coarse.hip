@@ -311,6 +311,11 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
     }   // next pair of this workgroup
 }
 
+
+#ifdef AOF_LAB_COARSE_WS
+#include AOF_LAB_COARSE_WS   // tools/coarse_ws_lab.hpp: the wave-specialised lab form of this kernel (measured, not kept)
+#endif
+
 }  // namespace
 
 size_t coarse_lds_bytes(const CoarseArgs &a)
@@ -362,13 +367,19 @@ int launch_coarse_fused(const CoarseArgs &a, void *stream)
         k.stagger_ticks = (int32_t)((int64_t)2 * a.w * a.h * 100 / kStaggerBytesPerUs);
     }
     const size_t lds = coarse_lds_bytes(a);
+    // one workgroup per CU (LDS); each walks pairs blockIdx.x, blockIdx.x + gridDim.x, ...
+    const int64_t wgs = a.n_pairs < k.first_generation ? a.n_pairs : k.first_generation;
+#ifdef AOF_LAB_COARSE_WS
+    {
+        int rc = 0;
+        if (lab_launch_coarse_ws(k, wgs, lds, stream, &rc)) return rc;
+    }
+#endif
     {   // (per launch, like the 16x16 kernel: the attribute belongs to the current device's code object)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
     }
-    // one workgroup per CU (LDS); each walks pairs blockIdx.x, blockIdx.x + gridDim.x, ...
-    const int64_t wgs = a.n_pairs < k.first_generation ? a.n_pairs : k.first_generation;
     hipLaunchKernelGGL(k_coarse, dim3((uint32_t)wgs), dim3(kThreads), lds, static_cast<hipStream_t>(stream), k);
     return (int)hipGetLastError();
 }
