@@ -3,7 +3,8 @@
 and image statistics; default, in-launch reduction, pruned, generic and separate-kernel device paths against the CPU oracle.
     python tools/fuzz_gpu.py [n_cases] [first_seed]            random configurations, two pairs per call
     python tools/fuzz_gpu.py [n_cases] [first_seed] many       the persistent coarse kernel: hundreds of pairs per call
-    python tools/fuzz_gpu.py [n_cases] [first_seed] resident   the per-call path: resident kernel, tagged graph, eager launches"""
+    python tools/fuzz_gpu.py [n_cases] [first_seed] resident   the per-call path: resident kernel, tagged graph, eager launches
+    python tools/fuzz_gpu.py [n_cases] [first_seed] sequence   aof_sequence_device: whole recordings against the oracle's calcFlow chain"""
 import importlib
 import os
 import sys
@@ -191,9 +192,114 @@ def resident(n_cases, seed0):
     print(f"per-call fuzz passed: {n_cases} sequences of 14 frames, {time.time() - t0:.0f} s")
 
 
+def sequence(n_cases, seed0):
+    """aof_sequence_device over random recordings: random small configurations (one and two levels, sparse and
+    dense grids), output rates from "every frame" to slower than the recording, time stamps with jitter, stalls
+    and 32-bit wrap-arounds, dark stretches, gyro increments -- records and MAVLink frames against the oracle's
+    calcFlow chain and the independent serializer of tests/test_mavlink.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_mavlink import py_frame
+    dev = torch.device("cuda:0")
+    t0 = time.time()
+    done = 0
+    for s in range(seed0, seed0 + n_cases):
+        rng = np.random.default_rng(880000 + s)
+        kw = small_case(rng)
+        p = aof.default_params(**kw)
+        if aof.check_params(p) != 0:
+            continue
+        n = int(rng.integers(1, 70))
+        cam_w, cam_h = p.width + 2 * int(rng.integers(0, 20)), p.height + 2 * int(rng.integers(0, 20))
+        reach = 9 if p.pyramid_levels == 2 else 4
+        frames, _ = synth.make_sequence(cam_w, cam_h, max(n, 2), reach, seed=s, max_step=reach - 1)
+        frames = frames[:n].copy()
+        if n > 8 and rng.random() < 0.4:
+            a = int(rng.integers(0, n - 4))
+            frames[a:a + int(rng.integers(1, 5))] = int(rng.integers(0, 256))       # flat frames: quality 0
+        steps = rng.integers(3000, 30000, n)
+        if rng.random() < 0.3:
+            steps[rng.integers(0, n, 3)] = 0                                        # repeated time stamps
+        times = np.concatenate([[0], np.cumsum(steps[1:])]).astype(np.int64)
+        if n > 4 and rng.random() < 0.4:
+            k = int(rng.integers(1, n))
+            times[k:] += (1 << 32) - int(times[k]) - int(rng.integers(0, 60000))   # the 32-bit time stamp wraps
+        if rng.random() < 0.2:
+            times += int(rng.integers(0, 1 << 33))                                  # not relative to the first frame at all
+        rate = int(rng.choice([0, -3, 1, 5, 15, 15, 30, 75, 500]))
+        offset = 0 if rng.random() < 0.1 else int(rng.integers(1, 1 << 50))
+        first_seq = int(rng.integers(0, 256))
+        gyro = np.zeros((n, 4), np.float32)
+        gyro[:, :3] = rng.normal(0, 0.01, (n, 3)).astype(np.float32)
+        gyro[:, 3] = rng.uniform(0, 0.05, n).astype(np.float32)
+        fx, fy = float(np.float32(rng.uniform(50, 900))), float(np.float32(rng.uniform(50, 900)))
+        sp = aof.sequence_params(cam_w, cam_h, p.width, p.height, fx, fy, rate, offset, int(rng.integers(1, 255)), int(rng.integers(1, 255)),
+                                 first_seq, derotate=(reach + 0.5, 0.01))
+        eng = aof.FlowEngine(p, 0)
+        use_gyro = bool(rng.random() < 0.85)
+        if not use_gyro:
+            sp.derotate = 0
+        ws, L = eng.sequence(sp, torch.from_numpy(frames).to(dev), torch.from_numpy(times).to(dev),
+                             torch.from_numpy(gyro).to(dev) if use_gyro else None)
+        torch.cuda.synchronize()
+        out = eng.sequence_outputs(sp, ws, L, n)
+        eng.close()
+        x0, y0 = cam_w // 2 - p.width // 2, cam_h // 2 - p.height // 2
+        cropped = np.ascontiguousarray(frames[:, y0:y0 + p.height, x0:x0 + p.width])
+        o = orc.Px4(orc.params_from(p), fx, fy, rate)
+        g = np.zeros(3, np.float64)
+        m = 0
+        bad = None
+        for k in range(n):
+            if use_gyro:
+                g += gyro[k, :3].astype(np.float64)
+            q, dt, ax, ay = o.calc_flow(cropped[k], int(times[k]) & 0xFFFFFFFF)
+            if q < 0:
+                continue
+            taken, g = g.copy(), np.zeros(3, np.float64)
+            if m >= len(out["records"]):
+                bad = f"record {m} missing"
+                break
+            r = out["records"][m]
+            want = (k, q, dt, np.float32(ax).tobytes(), np.float32(ay).tobytes(), np.float32(taken).tobytes())
+            got = (int(r["frame"]), int(r["quality"]), int(r["dt_us"]), r["flow_x"].tobytes(), r["flow_y"].tobytes(),
+                   np.array([r["gyro_x"], r["gyro_y"], r["gyro_z"]], np.float32).tobytes())
+            if got != want:
+                bad = f"record {m}: device {got[:3]} oracle {want[:3]}"
+                break
+            if offset:
+                sid, cid = sp.system_id, sp.component_id
+                f = bytearray(py_frame(offset, int(times[k]), dt, float(np.float32(ax)), float(np.float32(ay)),
+                                       tuple(float(v) for v in taken), q, (first_seq + m) & 0xFF))
+                # (py_frame writes the reference's ids 1 / 100: patch ours in and redo the checksum)
+                f[5], f[6] = sid, cid
+                from test_mavlink import x25
+                crc = x25(bytes([138]), x25(bytes(f[1:-2])))
+                f[-2], f[-1] = crc & 0xFF, crc >> 8
+                if out["mavlink"][m] != bytes(f):
+                    bad = f"frame {m} differs"
+                    break
+            elif len(out["mavlink"][m]) != 0:
+                bad = f"frame {m} sent without a vehicle time"
+                break
+            m += 1
+        if bad is None and m != len(out["records"]):
+            bad = f"{len(out['records'])} records, oracle {m}"
+        if bad is None and out["status"] != 0:
+            bad = f"status {out['status']}"
+        if bad:
+            print(f"MISMATCH sequence seed {s}: {bad}; n {n} rate {rate} cam {cam_w}x{cam_h} {kw}", flush=True)
+            sys.exit(1)
+        done += 1
+        if done % 50 == 0:
+            print(f"{done} sequence cases ok ({time.time() - t0:.0f} s)", flush=True)
+    print(f"sequence fuzz passed: {done} recordings of 1..69 frames, {time.time() - t0:.0f} s")
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if len(sys.argv) > 3 and sys.argv[3] == "sequence":
+        return sequence(n_cases, seed0)
     if len(sys.argv) > 3 and sys.argv[3] == "many":
         return many_pairs(n_cases, seed0)
     if len(sys.argv) > 3 and sys.argv[3] == "resident":
@@ -232,10 +338,31 @@ def main():
         small = small_eligible(p, aof.grid(p, 0), aof.grid(p, 1) if p.pyramid_levels == 2 else None)
         refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
         tp, tc = torch.from_numpy(prevs).to(dev), torch.from_numpy(curs).to(dev)
-        for mode in ("exhaustive", "fused_reduce", "pruned", "generic", "split"):
+        for mode in ("default", "exhaustive", "fused_reduce", "pruned", "generic", "split", "sequence_view"):
             if mode == "split" and p.pyramid_levels != 2 and not small:
                 continue   # (the separate kernels instead of k_coarse / k_flow_small)
+            if mode == "default" and p.tile != 16:
+                continue   # (8x8 contexts search exhaustively by default; 16x16 contexts in the adaptive mode)
+            if mode == "sequence_view":
+                # the two pairs as ONE sequence of three frames viewed twice (K1 once per frame): pair 0 = (prev0, cur0),
+                # pair 1 = (cur0, cur1)
+                seq = torch.from_numpy(np.stack([prevs[0], curs[0], curs[1]])).to(dev)
+                eng = aof.FlowEngine(p, 0)
+                if rng.random() < 0.5:
+                    eng.set_split_coarse(True)
+                b2, f2, _ = eng.flow_batch(seq[:-1], seq[1:], n_pairs=2, pair_stride=p.width * p.height)
+                torch.cuda.synchronize()
+                r1 = orc.flow_pair(po, curs[0], curs[1])
+                gb2, gf2 = aof.blocks_view(b2), aof.flows_view(f2)
+                if (gb2[0].tobytes() != refs[0]["blocks"].tobytes() or gf2[0].tobytes() != refs[0]["flow"].tobytes() or
+                        gb2[1].tobytes() != r1["blocks"].tobytes() or gf2[1].tobytes() != r1["flow"].tobytes()):
+                    print(f"MISMATCH seed {s} mode sequence_view ({eng.variant}): {kw}", flush=True)
+                    sys.exit(1)
+                eng.close()
+                continue
             eng = aof.FlowEngine(p, 0)
+            if mode == "exhaustive":
+                eng.set_search_mode(aof.SEARCH_EXHAUSTIVE)
             if mode == "split":
                 eng.set_split_coarse(True)
             elif mode == "generic":
@@ -310,7 +437,8 @@ def main():
         done += 1
         if done % 25 == 0:
             print(f"{done} cases ok ({time.time() - t0:.0f} s), skipped {skipped}, kernels {variants}", flush=True)
-    print(f"fuzz passed: {done} cases x 5 device paths (+ the separate kernels on two-level and small-pair cases), {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
+    print(f"fuzz passed: {done} cases x 6 device paths (+ the adaptive default on 16x16 cases, the separate kernels on two-level and "
+          f"small-pair cases), {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
