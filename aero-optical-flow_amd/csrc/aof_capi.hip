@@ -61,6 +61,7 @@ struct aof_ctx {
     bool graph_disabled;        // capture failed once: stay on the plain path
     bool capturing;
     bool split_coarse;          // run K1 / level-1 search / level-1 reduce as separate kernels
+    bool k1_ready;              // (set around one call by the sequence pipeline) K1's outputs are in the workspace already
     // resident form of the per-call path (aof_set_stream_resident): one workgroup stays on the device
     // and serves aof_stream_push_host through a mailbox in pinned memory
     bool resident_on;
@@ -341,6 +342,24 @@ int enqueue_level(aof_ctx *ctx, int level, SearchArgs a, const FlowTail &tail, u
     return 0;
 }
 
+// Arguments of the fused coarse kernel for pairs [first, first + n).
+CoarseArgs coarse_args(const aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, uint32_t *sums)
+{
+    const aof_params &p = ctx->params;
+    CoarseArgs c;
+    c.prev = v.prev + first * v.stride; c.cur = v.cur + first * v.stride; c.pair_stride = v.stride;
+    c.w = p.width; c.h = p.height; c.tile = p.tile; c.search = p.search; c.subpixel = p.subpixel;
+    c.grid = ctx->g1;
+    c.feature_threshold = p.feature_threshold;
+    c.value_threshold = value_threshold_u16(p);
+    c.sums = sums;
+    c.blocks = v.blocks1 + first * ctx->g1.blocks();
+    c.tail = flow_tail(ctx, 1, v.flows1 + first, nullptr);
+    c.n_pairs = n;
+    c.first_generation = ctx->cus; c.stagger_groups = 0; c.stagger_ticks = 0;   // stagger chosen by the launcher
+    return c;
+}
+
 // Coarse passes of pairs [first, first+n): pixel sums, level-1 frames, level-1 search and its
 // reduction (the predictor).  Nothing to do for one level without equalisation.
 int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, hipStream_t s)
@@ -353,17 +372,7 @@ int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, h
     if (two && !ctx->force_generic && !ctx->split_coarse) {
         // K1C: sums, pyramid, level-1 search and predictor of a pair in one workgroup, the
         // level-1 frames never leave LDS (workspace regions l1_prev / l1_cur stay untouched)
-        CoarseArgs c;
-        c.prev = v.prev + first * v.stride; c.cur = v.cur + first * v.stride; c.pair_stride = v.stride;
-        c.w = p.width; c.h = p.height; c.tile = p.tile; c.search = p.search; c.subpixel = p.subpixel;
-        c.grid = ctx->g1;
-        c.feature_threshold = p.feature_threshold;
-        c.value_threshold = value_threshold_u16(p);
-        c.sums = sums;
-        c.blocks = v.blocks1 + first * ctx->g1.blocks();
-        c.tail = flow_tail(ctx, 1, v.flows1 + first, nullptr);
-        c.n_pairs = n;
-        c.first_generation = ctx->cus; c.stagger_groups = 0; c.stagger_ticks = 0;   // stagger chosen by the launcher
+        const CoarseArgs c = coarse_args(ctx, v, first, n, sums);
         if (coarse_fused_supported(c)) {
             Timed t(ctx, AOF_K_PYRAMID, s);
             const int rc = launch_coarse_fused(c, s);
@@ -390,7 +399,7 @@ int enqueue_coarse(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, h
     } else {
         a.sequence = 0;
     }
-    {
+    if (!(sequence && ctx->k1_ready)) {   // (the sequence pipeline's ingest has left sums and level-1 frames already)
         Timed t(ctx, AOF_K_PYRAMID, s);
         const int rc = launch_pyramid(a, s);
         if (rc) return fail(ctx, -EIO, "pyramid launch: %s", hipGetErrorString((hipError_t)rc));
@@ -768,6 +777,46 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
     if (!rc) rc = enqueue_fine(ctx, v, 0, n_pairs, s);
     return rc;
 }
+
+}  // extern "C"
+
+namespace aof {
+
+// Would a sequence-view call (frames viewed twice, n_pairs = frames - 1) run K1 as a pass of its own?  Mirrors the
+// choices of aof_flow_batch_device / enqueue_coarse.  The sequence pipeline asks, because its ingest kernel can
+// leave K1's outputs (pixel sums at ws + L.sums, one level-1 frame per FRAME from ws + L.l1_prev on) itself.
+bool sequence_runs_k1(aof_ctx *ctx, const uint8_t *d_frames, int64_t n_pairs, void *d_workspace)
+{
+    const aof_params &p = ctx->params;
+    const bool two = p.pyramid_levels == 2, eq = p.mean_subtract != 0;
+    if (n_pairs < 1 || (!two && !eq)) return false;
+    aof_ws_layout L;
+    if (aof_workspace_layout(&p, n_pairs, &L)) return false;
+    const int64_t frame = (int64_t)p.width * p.height;
+    const BatchView v = batch_view(ctx, L, d_frames, d_frames + frame, frame, nullptr, nullptr, nullptr, d_workspace);
+    SmallArgs sm;
+    if (small_args(ctx, v, n_pairs, &sm)) return false;
+    if (two && !ctx->force_generic && !ctx->split_coarse &&
+        coarse_fused_supported(coarse_args(ctx, v, 0, n_pairs, v.sums)))
+        return false;
+    return true;
+}
+
+// aof_flow_batch_device on the sequence view of `d_frames`; k1_ready: K1's outputs are in the workspace already.
+int flow_sequence(aof_ctx *ctx, const uint8_t *d_frames, int64_t n_pairs, aof_flow *d_flows, void *d_workspace,
+                  size_t workspace_bytes, void *stream, bool k1_ready)
+{
+    const int64_t frame = (int64_t)ctx->params.width * ctx->params.height;
+    ctx->k1_ready = k1_ready;
+    const int rc = aof_flow_batch_device(ctx, d_frames, d_frames + frame, frame, n_pairs, nullptr, nullptr, d_flows,
+                                         d_workspace, workspace_bytes, stream);
+    ctx->k1_ready = false;
+    return rc;
+}
+
+}  // namespace aof
+
+extern "C" {
 
 int aof_set_split_coarse(aof_ctx *ctx, int on)
 {

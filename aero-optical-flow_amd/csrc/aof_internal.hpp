@@ -222,18 +222,29 @@ struct SequenceArgs {
     uint8_t *frames;               // [n_frames][AOF_SEQ_FRAME_BYTES], message m at + 56 m; or nullptr
     uint8_t *frame_len;            // [n_frames]
 };
-inline int sequence_rounds(int64_t n_frames)   // smallest R with 2^R > n_frames (the chain has at most that many hops)
+inline int sequence_rounds(int64_t n_frames)   // smallest R with 4^R > n_frames (the chain has at most that many hops)
 {
     int r = 0;
-    while ((1ll << r) <= n_frames) r++;
+    while ((1ll << (2 * r)) <= n_frames) r++;
     return r;
 }
 int launch_sequence_output(const SequenceArgs &a, void *stream);
+// (aof_capi.hip) the flow of a frame sequence for the pipeline: does the call run K1 as a pass of its own, and the
+// call itself with K1's outputs already in the workspace
+bool sequence_runs_k1(aof_ctx *ctx, const uint8_t *d_frames, int64_t n_pairs, void *d_workspace);
+int flow_sequence(aof_ctx *ctx, const uint8_t *d_frames, int64_t n_pairs, aof_flow *d_flows, void *d_workspace,
+                  size_t workspace_bytes, void *stream, bool k1_ready);
 int launch_reduce(const ReduceArgs &a, void *stream);
 int launch_derotate(const aof_derotate_params &p, const aof_flow *flows, const aof_gyro *gyro,
                     int64_t n, float *out, void *stream);
 int launch_ingest(const aof_ingest_params &p, const uint8_t *camera, int64_t camera_stride,
                   int64_t n_frames, uint8_t *cropped, int64_t cropped_stride, uint32_t *hist,
                   void *stream);
+// The sequence pipeline's ingest: the same pass also leaves every frame's level-1 image (l1: [n_frames] frames, or
+// nullptr) and adds its byte sums to the pixel-sum records of the pairs it belongs to (sums: [n_frames - 1][2][2],
+// zeroed here; or nullptr) -- what K1 would otherwise compute in a second pass over the cropped frames.
+bool ingest_pyramid_supported(const aof_ingest_params &p, const uint8_t *cropped, int64_t cropped_stride);
+int launch_ingest_pyramid(const aof_ingest_params &p, const uint8_t *camera, int64_t camera_stride, int64_t n_frames,
+                          uint8_t *cropped, int64_t cropped_stride, uint32_t *hist, uint8_t *l1, uint32_t *sums, void *stream);
 
 }  // namespace aof

@@ -103,14 +103,28 @@ int aof_sequence_device(aof_ctx *ctx, const aof_sequence_params *sp, const uint8
     uint8_t *cropped = ws + L.cropped;
     aof_flow *flows = reinterpret_cast<aof_flow *>(ws + L.flows);
 
-    // 1. sensor frames -> the cropped sequence + exposure histograms (mainloop.cpp:295-298,203-214)
-    rc = aof_ingest_batch_device(&sp->ingest, d_camera, camera_stride, n_frames, cropped, frame,
-                                 reinterpret_cast<uint32_t *>(ws + L.exposure), stream);
-    if (rc) return rc;
+    // 1. sensor frames -> the cropped sequence + exposure histograms (mainloop.cpp:295-298,203-214).  Where the flow
+    //    would run K1 (pixel sums, 2x2 pyramid) as a pass of its own over the cropped frames, the ingest kernel
+    //    leaves K1's outputs itself -- once per FRAME, out of the registers the crop passes through.
+    uint8_t *flow_ws = ws + L.scratch + s.flow_ws;
+    uint32_t *exposure = reinterpret_cast<uint32_t *>(ws + L.exposure);
+    bool k1_ready = false;
+    if (n_frames > 1 && ingest_pyramid_supported(sp->ingest, cropped, frame) && sequence_runs_k1(ctx, cropped, n_frames - 1, flow_ws)) {
+        aof_ws_layout FL;
+        rc = aof_workspace_layout(&p, n_frames - 1, &FL);
+        if (rc) return rc;
+        rc = launch_ingest_pyramid(sp->ingest, d_camera, camera_stride, n_frames, cropped, frame, exposure,
+                                   p.pyramid_levels == 2 ? flow_ws + FL.l1_prev : nullptr,
+                                   p.mean_subtract ? reinterpret_cast<uint32_t *>(flow_ws + FL.sums) : nullptr, stream);
+        if (rc) return -EIO;
+        k1_ready = true;
+    } else {
+        rc = aof_ingest_batch_device(&sp->ingest, d_camera, camera_stride, n_frames, cropped, frame, exposure, stream);
+        if (rc) return rc;
+    }
     // 2. flow of consecutive frames: the same buffer viewed twice (frame k is cur of pair k-1, prev of pair k)
     if (n_frames > 1) {
-        rc = aof_flow_batch_device(ctx, cropped, cropped + frame, frame, n_frames - 1, nullptr, nullptr, flows,
-                                   ws + L.scratch + s.flow_ws, s.flow_ws_bytes, stream);
+        rc = flow_sequence(ctx, cropped, n_frames - 1, flows, flow_ws, s.flow_ws_bytes, stream, k1_ready);
         if (rc) return rc;
     }
     // 3. + 5. limiter, gyro sums, angles, records and MAVLink frames

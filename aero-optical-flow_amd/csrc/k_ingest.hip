@@ -69,10 +69,22 @@ __device__ __forceinline__ void flush_counts(uint32_t *s_hist, LaneCounts &n)
     for (int k = 0; k < 5; k++) n.w[k] = 0;
 }
 
+// PYRAMID (the sequence pipeline, aof_sequence_device): the lane's four pieces are two vertically adjacent PAIRS
+// of rows, and what K1 would compute from the cropped frame in a second pass over it comes out of the same
+// registers: the frame's 2x2-box level-1 image (one per FRAME: a sequence's level-1 frames form a sequence of their
+// own) and its level-0 / level-1 byte sums, added to the pixel-sum records of the two pairs the frame belongs to
+// (prev of pair f, cur of pair f - 1; [pair][prev, cur][level]).
+struct IngestPyramid {
+    uint8_t *l1;          // [n_frames][crop_h / 2][crop_w / 2], or nullptr (sums only)
+    uint32_t *sums;       // [n_frames - 1][2][2] zeroed by the launcher, or nullptr
+    int64_t n_frames;
+};
+
+template <bool PYRAMID>
 __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const uint8_t *camera,
                                                      int64_t camera_stride, uint8_t *cropped,
                                                      int64_t cropped_stride, uint32_t *hist, int nstrips,
-                                                     int vec)
+                                                     int vec, IngestPyramid pyr)
 {
     __shared__ uint32_t s_hist[AOF_EXPOSURE_BINS];
     __shared__ uint2 s_onehot[256];   // grey value -> one-hot increment of a lane's table sums (bins 0..4, bins 5..9)
@@ -87,6 +99,8 @@ __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const 
     __syncthreads();
     LaneCounts cnt = {{0u, 0u, 0u, 0u, 0u}};
     uint32_t sum_lo = 0, sum_hi = 0;  // table sums since the last widening
+    uint32_t pyr_sum0 = 0, pyr_sum1 = 0;   // PYRAMID: the lane's share of the frame's level-0 / level-1 byte sums
+    (void)pyr_sum0; (void)pyr_sum1;
 
     const int x0 = p.camera_width / 2 - p.crop_width / 2, y0 = p.camera_height / 2 - p.crop_height / 2;
     int mx0 = p.crop_width / 2 - AOF_EXPOSURE_MASK_SIZE / 2, my0 = p.crop_height / 2 - AOF_EXPOSURE_MASK_SIZE / 2;
@@ -109,7 +123,13 @@ __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const 
             bool act[kUnroll];
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) {
-                const int it = base + u * kThreads + tid;
+                int it = base + u * kThreads + tid;
+                if (PYRAMID) {
+                    // pieces 2q and 2q + 1 of a lane are rows 2r and 2r + 1 of ONE row pair (items counted in row
+                    // pairs x pieces x 2: row_begin and the strip height are even)
+                    const int pr = base / 2 + (u >> 1) * kThreads + tid;   // (row pair, piece) index
+                    it = pr < items / 2 ? (2 * (pr / pieces) + (u & 1)) * pieces + pr % pieces : items;
+                }
                 act[u] = it < items;
                 ys[u] = row_begin + (act[u] ? it / pieces : 0);
                 xs[u] = act[u] ? (it % pieces) * 16 : 0;
@@ -143,8 +163,39 @@ __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const 
                 if (hist && round % kLanePieces == kLanePieces - 1) { widen_add(cnt, sum_lo, sum_hi); sum_lo = sum_hi = 0; }
                 if (hist && round % kWavePieces == kWavePieces - 1) flush_counts(s_hist, cnt);
             }
+            if constexpr (PYRAMID) {
+#pragma unroll
+                for (int q = 0; q < kUnroll / 2; q++) {
+                    if (!act[2 * q]) continue;   // (a row pair is active as a whole)
+                    const uint4 r0 = v[2 * q], r1 = v[2 * q + 1];
+                    pyr_sum0 = byte_sum(r0.x, pyr_sum0); pyr_sum0 = byte_sum(r0.y, pyr_sum0);
+                    pyr_sum0 = byte_sum(r0.z, pyr_sum0); pyr_sum0 = byte_sum(r0.w, pyr_sum0);
+                    pyr_sum0 = byte_sum(r1.x, pyr_sum0); pyr_sum0 = byte_sum(r1.y, pyr_sum0);
+                    pyr_sum0 = byte_sum(r1.z, pyr_sum0); pyr_sum0 = byte_sum(r1.w, pyr_sum0);
+                    const uint32_t p0 = box2(r0.x, r1.x), p1 = box2(r0.y, r1.y);
+                    const uint32_t p2 = box2(r0.z, r1.z), p3 = box2(r0.w, r1.w);
+                    uint2 o;
+                    o.x = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
+                    o.y = __builtin_amdgcn_perm(p3, p2, 0x06040200u);
+                    pyr_sum1 = byte_sum(o.x, pyr_sum1);
+                    pyr_sum1 = byte_sum(o.y, pyr_sum1);
+                    if (pyr.l1)
+                        *reinterpret_cast<uint2 *>(pyr.l1 + frame * (int64_t)(p.crop_width / 2) * (p.crop_height / 2) +
+                                                   (int64_t)(ys[2 * q] / 2) * (p.crop_width / 2) + xs[2 * q] / 2) = o;
+                }
+            }
         }
         if (hist) { widen_add(cnt, sum_lo, sum_hi); flush_counts(s_hist, cnt); }
+        if constexpr (PYRAMID) {
+            if (pyr.sums) {
+                pyr_sum0 = wave_sum_u32(pyr_sum0);
+                pyr_sum1 = wave_sum_u32(pyr_sum1);
+                if ((tid & 63) == 0) {
+                    if (frame < pyr.n_frames - 1) { atomicAdd(&pyr.sums[frame * 4 + 0], pyr_sum0); atomicAdd(&pyr.sums[frame * 4 + 1], pyr_sum1); }
+                    if (frame > 0) { atomicAdd(&pyr.sums[(frame - 1) * 4 + 2], pyr_sum0); atomicAdd(&pyr.sums[(frame - 1) * 4 + 3], pyr_sum1); }
+                }
+            }
+        }
     } else {
         const int items = (row_end - row_begin) * p.crop_width;
         for (int it = tid; it < items; it += kThreads) {
@@ -179,8 +230,35 @@ int launch_ingest(const aof_ingest_params &p, const uint8_t *camera, int64_t cam
     }
     const int vec = (p.crop_width % 16 == 0) && (!cropped || (reinterpret_cast<uintptr_t>(cropped) % 16 == 0 &&
                                                                 cropped_stride % 16 == 0));
-    hipLaunchKernelGGL(k_ingest, dim3((uint32_t)(n_frames * nstrips)), dim3(kThreads), 0, s, p, camera,
-                       camera_stride, cropped, cropped_stride, hist, nstrips, vec);
+    hipLaunchKernelGGL(k_ingest<false>, dim3((uint32_t)(n_frames * nstrips)), dim3(kThreads), 0, s, p, camera,
+                       camera_stride, cropped, cropped_stride, hist, nstrips, vec, IngestPyramid{nullptr, nullptr, 0});
+    return (int)hipGetLastError();
+}
+
+// The sequence pipeline's ingest: crop + exposure histogram + the frame's level-1 image and pixel sums in one pass.
+bool ingest_pyramid_supported(const aof_ingest_params &p, const uint8_t *cropped, int64_t cropped_stride)
+{
+    return p.crop_width % 16 == 0 && p.crop_height % 2 == 0 && cropped && reinterpret_cast<uintptr_t>(cropped) % 16 == 0 &&
+           cropped_stride % 16 == 0;   // (strips of kRowsPerBlock rows: even)
+}
+
+int launch_ingest_pyramid(const aof_ingest_params &p, const uint8_t *camera, int64_t camera_stride, int64_t n_frames,
+                          uint8_t *cropped, int64_t cropped_stride, uint32_t *hist, uint8_t *l1, uint32_t *sums, void *stream)
+{
+    if (n_frames == 0) return 0;
+    if (!ingest_pyramid_supported(p, cropped, cropped_stride)) return (int)hipErrorInvalidValue;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nstrips = (p.crop_height + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (hist && nstrips > 1) {
+        const int rc = launch_zero_words(hist, n_frames * AOF_EXPOSURE_BINS, stream);
+        if (rc) return rc;
+    }
+    if (sums && n_frames > 1) {
+        const int rc = launch_zero_words(sums, (n_frames - 1) * 4, stream);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_ingest<true>, dim3((uint32_t)(n_frames * nstrips)), dim3(kThreads), 0, s, p, camera,
+                       camera_stride, cropped, cropped_stride, hist, nstrips, 1, IngestPyramid{l1, n_frames > 1 ? sums : nullptr, n_frames});
     return (int)hipGetLastError();
 }
 

@@ -12,8 +12,8 @@
 // the previous publication i with (float)(t_j - t_i) > period.  That is a linked list through the frames
 // (next[i]), entered at a virtual start node with time 0 (time_last_pub's initial value): k_limit_next builds
 // the list (one lane per frame, a short forward scan), k_limit_double marks the nodes on the chain from the
-// start by pointer doubling (log2(n) rounds: reached nodes mark their 2^r-th successor, every node learns its
-// 2^(r+1)-th) and numbers them along the way (rank = position on the chain = index of the node's message),
+// start by pointer jumping (log4(n) rounds: marked nodes mark their d-th, 2d-th and 3d-th successors, every node
+// learns its 4d-th) and numbers them along the way (rank = position on the chain = index of the node's message),
 // and k_sequence_emit -- one lane per published frame -- sums its segment IN FRAME ORDER (float adds are not
 // associative: the host sums in that order), converts, fills and packs.  Every float operation is the host's,
 // in the host's order: the frames are byte-identical to driving the C++ facade frame by frame.
@@ -59,20 +59,27 @@ __global__ __launch_bounds__(kThreads) void k_limit_next(SequenceArgs a)
     a.rank[i] = 0;
 }
 
-// One round of pointer doubling: in -> out.  A node marked in an EARLIER round marks its successor at the
-// round's distance and numbers it; every node doubles its own jump.
+// One round of pointer QUADRUPLING: in -> out.  Entering round r every node knows its d-th successor (d = 4^(r-1))
+// and the nodes at fewer than d hops from the start are marked.  A node marked in an EARLIER round marks and
+// numbers its successors at d, 2d and 3d hops (the marked set grows to 4d; every position has exactly one
+// writer), and every node learns its 4d-th successor: half the launches of plain doubling.
 __global__ __launch_bounds__(kThreads) void k_limit_double(SequenceArgs a, int round)
 {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i > a.n_frames) return;
     const int in = (round + 1) & 1, out = round & 1;   // round 1 reads buffer 0
-    const uint32_t j = a.jump[in][i], h = a.hops[in][i];
-    a.jump[out][i] = a.jump[in][j];
-    a.hops[out][i] = h + a.hops[in][j];
+    const uint32_t j1 = a.jump[in][i], h1 = a.hops[in][i];
+    const uint32_t j2 = a.jump[in][j1], h2 = a.hops[in][j1];
+    const uint32_t j3 = a.jump[in][j2], h3 = a.hops[in][j2];
+    a.jump[out][i] = a.jump[in][j3];
+    a.hops[out][i] = h1 + h2 + h3 + a.hops[in][j3];
     const uint8_t mark = a.reached[i];
-    if (mark != 0 && mark <= round && a.reached[j] == 0) {
-        a.rank[j] = a.rank[i] + h;
-        a.reached[j] = (uint8_t)(round + 1);
+    if (mark != 0 && mark <= round) {
+        const uint32_t r0 = a.rank[i];
+        // (the END node absorbs every jump past the last publication: all of its writers carry the same rank)
+        if (a.reached[j1] == 0) { a.rank[j1] = r0 + h1; a.reached[j1] = (uint8_t)(round + 1); }
+        if (j2 != j1 && a.reached[j2] == 0) { a.rank[j2] = r0 + h1 + h2; a.reached[j2] = (uint8_t)(round + 1); }
+        if (j3 != j2 && a.reached[j3] == 0) { a.rank[j3] = r0 + h1 + h2 + h3; a.reached[j3] = (uint8_t)(round + 1); }
     }
 }
 

@@ -351,7 +351,7 @@ def bench_sequence(args, aof, device, rank, world, dist):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "seq: aof_sequence_device over a resident recording", "frames_per_gpu": n,
                        "records_published": int(len(out["records"])), "frames_sent": out["frames_sent"],
-                       "limiter_rounds": int(np.ceil(np.log2(n + 1)))},
+                       "limiter_rounds": int(np.ceil(np.log(n + 1) / np.log(4)))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "whole pipeline (all kernels of one call)",
                          "kernel_ms": round(step_ms, 5), "algorithmic_bytes_per_frame": alg, "frames_per_launch": n}}

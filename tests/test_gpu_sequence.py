@@ -61,6 +61,10 @@ CASES = [
     dict(cls="px4", crop=(64, 64), cam=(64, 64), n=60, rate=30, seed=6, wrap=True),       # crop == sensor; u32 wrap of the time stamps
     dict(cls="px4", crop=(64, 64), cam=(160, 120), n=33, rate=10, seed=7, offset=0),      # vehicle time unknown: nothing is sent
     dict(cls="opencv", crop=(128, 128), cam=(320, 240), n=50, rate=200, seed=8, dark=True),   # rate above the frame rate; frames without valid flow
+    # more than 128 pairs: the flow runs its separate kernels, and the ingest kernel leaves K1's outputs (pixel sums,
+    # one level-1 frame per frame) itself -- crop window at an odd byte offset of the sensor rows, and crop == sensor
+    dict(cls="opencv", crop=(128, 128), cam=(322, 250), n=260, rate=15, seed=9, dark=True),
+    dict(cls="opencv", crop=(128, 128), cam=(128, 128), n=200, rate=30, seed=10),
 ]
 
 

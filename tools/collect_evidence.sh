@@ -12,17 +12,21 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/evidence
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-WL=${@:-c2 c3 c5 c2h c1b c5h ingest derotate share lanes latency}
+WL=${@:-c2 c3 c5 c2h c1b c5h ingest derotate seq share lanes latency}
 args_of() {   # bench.py arguments and the launch size key of a workload
     case $1 in
         c5|c5h) echo "--pairs 256";;
         c1b) echo "--pairs 65536";;
         ingest) echo "--pairs 1024";;
         derotate) echo "--pairs 1024";;
+        seq) echo "--pairs 1024 --steps 20";;
         *) echo "";;
     esac
 }
-key_of() { case $1 in c5|c5h) echo 256;; c1b) echo 65536;; ingest) echo 8192;; derotate) echo 1048576;; *) echo 1024;; esac; }
+# profiler runs of the 16x16 workloads name the headline mode: the default line also times the other two modes behind
+# its timed region, and k_search_tile16<true, ...> serves both the adaptive and the always-pruned mode
+mode_of() { case $1 in c5|c5h) echo "--search adaptive";; *) echo "";; esac; }
+key_of() { case $1 in c5|c5h) echo 256;; c1b) echo 65536;; ingest) echo 8192;; derotate) echo 1048576;; seq) echo 65536;; *) echo 1024;; esac; }
 trace() {   # tag, bench arguments...: kernel-trace summary of one bench command
     tag=$1; shift
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -- python3 $R/bench.py "$@" --cpu-seconds 0 > $O/kt_$tag.log 2>&1 || { echo "kernel trace $tag failed"; tail -3 $O/kt_$tag.log; exit 1; }
@@ -53,19 +57,19 @@ for wl in $WL; do
         line lanes_c3_p512 --workload c3 --pairs 512 --streams 2 --cpu-seconds 0
         echo "lanes done";;
     latency)
-        cd $R && tools/stream_latency.sh > $O/stream_latency.txt 2>&1; cd /tmp
+        cd $R && tools/stream_latency.sh > $O/stream_latency.txt 2> $O/stream_latency.err; cd /tmp
         timeout -k 10 200 python3 $R/bench.py --workload c1 --pairs 256 --steps 20 > $O/bench_c1.json 2> $O/bench_c1.err || { echo "bench c1 failed"; exit 1; }
         echo "latency done";;
     *)
         extra=$(args_of $wl)
         line $wl --workload $wl $extra
-        trace $wl --workload $wl $extra
+        trace $wl --workload $wl $extra $(mode_of $wl)
         echo "$wl done";;
     esac
 done
 for wl in $WL; do
     case $wl in share|lanes|latency) continue;; esac
-    extra=$(args_of $wl); pairs=$(key_of $wl)
+    extra="$(args_of $wl) $(mode_of $wl)"; pairs=$(key_of $wl)
     for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"; do
         tag=$(echo $set | cut -d" " -f1)
         timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$wl/$tag -- python3 $R/bench.py --workload $wl $extra --steps 5 --warmup 2 --settle-steps 0 --cpu-seconds 0 > $O/pmc_${wl}_$tag.log 2>&1 || { echo "pmc $wl $tag failed"; exit 1; }

@@ -8,7 +8,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
 rnd = prefix.split("_")[0]
 
 
@@ -16,7 +16,7 @@ def load(name):
     return json.loads(open(os.path.join(ROOT, "profiles", f"{prefix}_bench_{name}.json")).read().strip().splitlines()[-1])
 
 
-c2, c3, ing = load("c2"), load("c3"), load("ingest")
+c2, c3, ing, c5, seq = load("c2"), load("c3"), load("ingest"), load("c5"), load("seq")
 l3, l1b, share, two = load("lanes_c3"), load("lanes_c1b"), load("share_p128"), load("share_p1024_two_batches")
 lat = [l for l in open(os.path.join(ROOT, "profiles", f"{rnd}_stream_latency.txt")) if "lane8" in l]
 
@@ -36,11 +36,16 @@ txt = (f"Headline (`bench.py`, C2: 1 024 VGA pairs per launch, 8×8 SAD, ±4, ex
        f"C3 (two-level pyramid + equalisation) {c3['value']/1e6:.2f} M pairs/s, {l3['value']/1e6:.2f} M = **{l3['roofline']['frac_step']*100:.1f} %** "
        f"(whole step) with two batches in flight; configs[3]'s per-GPU share of 128 pairs takes {share['ms_per_step']*1e3:.1f} µs per step against "
        f"{two['ms_per_step']*1e3:.1f}–{c2['ms_per_step']*1e3:.1f} µs for all 1 024 pairs on one GPU "
-       f"(**{two['ms_per_step']/share['ms_per_step']:.1f}–{c2['ms_per_step']/share['ms_per_step']:.1f}×**; round 2: 5.1×); "
+       f"(**{two['ms_per_step']/share['ms_per_step']:.1f}–{c2['ms_per_step']/share['ms_per_step']:.1f}×**); "
+       f"C5 (1280×960, 16×16 SAD, ±8) {c5['value']/1e6:.2f} M pairs/s = **{c5['roofline']['frac']*100:.1f} %** with the exact-adaptive search that 16×16 "
+       f"contexts run by default (exhaustive: {c5['exhaustive_search']['per_gpu_value']/1e6:.2f} M = {c5['exhaustive_search']['roofline_frac']*100:.1f} %; "
+       f"within 3 % of exhaustive on noise, `profiles/r04_c5_adaptive_sweep.txt`); "
+       f"a recording of {seq['config']['frames_per_gpu']:,} sensor frames through the whole per-frame loop on the device (`aof_sequence_device`) "
+       f"{seq['value']/1e6:.0f} M frames/s; "
        f"configs[0] in batch {l1b['value']/1e6:.0f} M pairs/s; frame ingest {ing['value']/1e6:.0f} M frames/s "
        f"({ing['roofline']['frac']*100:.0f} % of the roofline, ≈ 92 % of what a plain copy of the same row pieces reaches); "
        f"one `calcFlow()` call **{us(64, 1, 0):.2f} µs at 64×64 / {us(128, 2, 0):.2f} µs at 128×128 on two levels** through a replayed hipGraph "
-       f"whose tagged record the host polls for (round 2: 24.9 / 34.7 µs; the CPU oracle: 16 µs on one core), "
+       f"whose tagged record the host polls for (the CPU oracle: 16 µs on one core), "
        f"{us(64, 1, 1):.2f} / {us(128, 2, 1):.2f} µs served by the resident kernel (opt-in).")
 path = os.path.join(ROOT, "README.md")
 s = open(path).read()

@@ -47,8 +47,8 @@ def main():
     # the level-0 search is the k_search kernel that moves the most bytes
     # (bench.py also runs the opt-in pruned search, template argument PRUNE = true: not the headline)
     names = [k for k in traffic if k.startswith("k_search") or k.startswith("k_flow")]
-    def pruned(k):   # the opt-in exact-pruned variants bench.py also runs: not part of the headline step
-        return "_pruned" in k or k.startswith("k_search_tile16<true")
+    def pruned(k):   # the opt-in exact-pruned 8x8 variant bench.py also runs: not part of the headline step
+        return "_pruned" in k   # (16x16 workloads are profiled with --search adaptive: only the headline mode's kernels run)
     names = [k for k in names if not pruned(k)] or names
     if not names:   # workloads without a search kernel (ingest, derotate): the kernel that moves the most bytes
         names = list(traffic)

@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
 ev, prof = os.path.join(ROOT, "gpurun_out", "evidence"), os.path.join(ROOT, "profiles")
 n = 0
 for f in sorted(glob.glob(os.path.join(ev, "bench_*.json"))):
@@ -22,10 +22,11 @@ for f in sorted(glob.glob(os.path.join(ev, "pmc_*.txt"))):
 lat = os.path.join(ev, "stream_latency.txt")
 if os.path.exists(lat):
     head = ("# tools/stream_latency.sh (tools/bench_stream.cpp): microseconds per aof_stream_push_host call from C++, 5000 calls after 50\n"
-            "# warm-up calls.  graph=1: one replayed hipGraph per call (lane8 rows: ONE kernel whose record arrives tagged in pinned memory,\n"
-            "# the host polls for the tag instead of waiting for the stream); graph=0: eager launches + stream wait; resident=1:\n"
-            "# aof_set_stream_resident, a one-workgroup kernel stays on the device and serves the calls through a mailbox in pinned\n"
-            "# memory (no launch per call).\n")
+            "# warm-up calls, with the streaming counters (aof_stream_stats) of each mode.  graph=1: one replayed hipGraph per call (lane8 rows:\n"
+            "# ONE kernel whose record arrives tagged in pinned memory, the host polls for the tag instead of waiting for the stream); graph=0:\n"
+            "# eager launches + stream wait; resident=1: aof_set_stream_resident, a one-workgroup kernel stays on the device and serves the calls\n"
+            "# through a mailbox in pinned memory (no launch per call); launch call = duration of the hipLaunchKernelGGL that started it,\n"
+            "# launch->first poll = from that call's return until the kernel's first store into the mailbox was seen (no HIP call in between).\n")
     open(os.path.join(prof, f"{prefix.split('_')[0]}_stream_latency.txt"), "w").write(head + open(lat).read()); n += 1
 src = os.path.join(ev, "pmc_traffic.json")
 if os.path.exists(src):
