@@ -23,6 +23,17 @@
 
 namespace aof {
 
+// PYRAMID (the sequence pipeline, aof_sequence_device): the lane's four pieces are two vertically adjacent PAIRS
+// of rows, and what K1 would compute from the cropped frame in a second pass over it comes out of the same
+// registers: the frame's 2x2-box level-1 image (one per FRAME: a sequence's level-1 frames form a sequence of their
+// own) and its level-0 / level-1 byte sums, added to the pixel-sum records of the two pairs the frame belongs to
+// (prev of pair f, cur of pair f - 1; [pair][prev, cur][level]).
+struct IngestPyramid {
+    uint8_t *l1;          // [n_frames][crop_h / 2][crop_w / 2], or nullptr (sums only)
+    uint32_t *sums;       // [n_frames - 1][2][2] zeroed by the launcher, or nullptr
+    int64_t n_frames;
+};
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -68,17 +79,6 @@ __device__ __forceinline__ void flush_counts(uint32_t *s_hist, LaneCounts &n)
 #pragma unroll
     for (int k = 0; k < 5; k++) n.w[k] = 0;
 }
-
-// PYRAMID (the sequence pipeline, aof_sequence_device): the lane's four pieces are two vertically adjacent PAIRS
-// of rows, and what K1 would compute from the cropped frame in a second pass over it comes out of the same
-// registers: the frame's 2x2-box level-1 image (one per FRAME: a sequence's level-1 frames form a sequence of their
-// own) and its level-0 / level-1 byte sums, added to the pixel-sum records of the two pairs the frame belongs to
-// (prev of pair f, cur of pair f - 1; [pair][prev, cur][level]).
-struct IngestPyramid {
-    uint8_t *l1;          // [n_frames][crop_h / 2][crop_w / 2], or nullptr (sums only)
-    uint32_t *sums;       // [n_frames - 1][2][2] zeroed by the launcher, or nullptr
-    int64_t n_frames;
-};
 
 template <bool PYRAMID>
 __global__ __launch_bounds__(kThreads) void k_ingest(aof_ingest_params p, const uint8_t *camera,

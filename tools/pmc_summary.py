@@ -21,7 +21,7 @@ def main():
             k = r["Kernel_Name"]
             if "aof::" not in k:
                 continue
-            k = k.split("(anonymous namespace)::")[-1].split("(")[0]
+            k = k.split("(anonymous namespace)::", 1)[-1].split("(")[0]   # the kernel's own name, not a parameter type's
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines = [f"# rocprofv3 --pmc summary, workload {workload}, {pairs} pairs per launch (means over launches)"]
     traffic = {}
