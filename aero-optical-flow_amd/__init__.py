@@ -142,6 +142,7 @@ def _load():
         "aof_set_stream_graph": (C.c_int, [VP, C.c_int]),
         "aof_set_stream_resident": (C.c_int, [VP, C.c_int]),
         "aof_stream_get_stats": (C.c_int, [VP, P(StreamStats)]),
+        "aof_debug_resident_fault": (C.c_int, [VP, C.c_int, C.c_uint32]),
         "aof_set_vote_deadline_us": (C.c_int, [VP, C.c_uint32]),
         "aof_ingest_batch_device": (C.c_int, [P(IngestParams), VP, I64, I64, VP, I64, VP, VP]),
         "aof_sequence_layout": (C.c_int, [P(Params), P(SequenceParams), I64, P(SeqLayout)]),
@@ -514,6 +515,10 @@ class FlowEngine:
         st = StreamStats()
         self._check(lib.aof_stream_get_stats(self._ctx, C.byref(st)))
         return st.as_dict()
+
+    def debug_resident_fault(self, deaf=True, stop_wait_us=0):
+        """Fault injection: resident kernels ignore the request to leave; the library's wait for them is shortened."""
+        self._check(lib.aof_debug_resident_fault(self._ctx, int(deaf), int(stop_wait_us)))
 
     def set_vote_deadline_us(self, microseconds):
         """Test knob: deadline of the finaliser waves of the in-launch reduction."""

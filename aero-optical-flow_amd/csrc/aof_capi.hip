@@ -71,6 +71,8 @@ struct aof_ctx {
     ResidentBox *box;           // pinned, device-visible
     uint32_t rseq;              // number of the last request posted
     uint32_t rlaunches;         // resident kernel instances started on `box`
+    bool rdeaf;                 // fault injection (aof_debug_resident_fault): the next instances ignore the stop bit
+    double rstop_wait_s;        // how long resident_stop waits for the exit flag (1 s; the fault injection shortens it)
     uint32_t rframe_req[2];     // request at which pinned frame b was posted as the newest frame, 0 = written otherwise
     aof_stream_stats stats;     // aof_stream_get_stats
     // device -> host fault word (pinned, its own allocation): a kernel that gave up on a device-side wait
@@ -499,7 +501,7 @@ bool resident_stop(aof_ctx *ctx)
     // launch-to-first-poll latency in aof_stream_stats is measured with the host spinning on pinned memory
     // and nothing else).
     const auto t0 = std::chrono::steady_clock::now();
-    while (__atomic_load_n(&box->running, __ATOMIC_ACQUIRE) && seconds_since(t0) < 1.0) {
+    while (__atomic_load_n(&box->running, __ATOMIC_ACQUIRE) && seconds_since(t0) < ctx->rstop_wait_s) {
     }
     hipError_t e = hipSuccess;
     if (!__atomic_load_n(&box->running, __ATOMIC_ACQUIRE)) {
@@ -510,9 +512,9 @@ bool resident_stop(aof_ctx *ctx)
             return true;
         }
     }
-    std::fprintf(stderr, "aof: the resident kernel did not leave within 1 s of being asked to (launch %u, started %u, "
+    std::fprintf(stderr, "aof: the resident kernel did not leave within %.0f ms of being asked to (launch %u, started %u, "
                          "served %u, exited at %u, on device %u, stream: %s): its buffers are abandoned\n",
-                 ctx->rlaunches, (unsigned)box->started, (unsigned)box->done, (unsigned)box->exited, (unsigned)box->running,
+                 ctx->rstop_wait_s * 1e3, ctx->rlaunches, (unsigned)box->started, (unsigned)box->done, (unsigned)box->exited, (unsigned)box->running,
                  e == hipSuccess ? hipGetErrorString(hipStreamQuery(ctx->rstream)) : hipGetErrorString(e));
     ctx->resident_lost = true;
     ctx->stats.resident_lost++;
@@ -564,6 +566,7 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
         ctx->votes_pairs = kVotePairs;
     }
     ctx->vote_deadline_ticks = kVoteDeadlineTicks;
+    ctx->rstop_wait_s = 1.0;
     ctx->separate_reduce = true;   // the in-launch reduction is opt-in (aof_set_reduce_fusion)
     // 16x16 tiles: exact pruning wherever the block row's own probe says it pays (include/aof.h)
     ctx->search_mode = p->tile == 16 ? AOF_SEARCH_ADAPTIVE : AOF_SEARCH_EXHAUSTIVE;
@@ -1213,7 +1216,7 @@ static int stream_push_resident(aof_ctx *ctx, const uint8_t *frame, aof_flow *fl
             const auto l0 = std::chrono::steady_clock::now();
             const int lrc = launch_flow_resident(sm, box, ctx->h_flow, ctx->h_frames[0], ctx->h_frames[1],
                                                  __atomic_load_n(&box->done, __ATOMIC_ACQUIRE), ++ctx->rlaunches,
-                                                 kResidentIdleTicks, kResidentLifeTicks, ctx->rstream);
+                                                 kResidentIdleTicks, kResidentLifeTicks, ctx->rdeaf, ctx->rstream);
             if (lrc) {
                 // nothing was enqueued: the flag is the host's to take back
                 __atomic_store_n(&box->running, 0u, __ATOMIC_RELEASE);
@@ -1267,6 +1270,14 @@ int aof_set_stream_resident(aof_ctx *ctx, int on)
     if (on < 0) return (ctx->box && __atomic_load_n(&ctx->box->running, __ATOMIC_ACQUIRE)) ? 1 : 0;
     if (!on) { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }
     ctx->resident_on = on != 0;
+    return 0;
+}
+
+int aof_debug_resident_fault(aof_ctx *ctx, int deaf, uint32_t stop_wait_us)
+{
+    if (!ctx) return -EINVAL;
+    ctx->rdeaf = deaf != 0;
+    ctx->rstop_wait_s = stop_wait_us ? stop_wait_us * 1e-6 : 1.0;
     return 0;
 }
 

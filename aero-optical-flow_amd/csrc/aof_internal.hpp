@@ -200,7 +200,7 @@ inline unsigned long long resident_word(uint32_t request, int slot, uint32_t pre
 // host_record: the pinned 16-byte record the host polls (top byte of `count` = low byte of the request).
 int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_record, const uint8_t *frame_a,
                          const uint8_t *frame_b, uint32_t served, uint32_t launch_no, uint64_t idle_ticks,
-                         uint64_t life_ticks, void *stream);
+                         uint64_t life_ticks, bool deaf, void *stream);
 // The output side of a frame sequence (k_sequence.hip): rate limiter, gyro sums, angles, OPTICAL_FLOW_RAD frames.
 constexpr int64_t kLimitScanFrames = 4096;   // a publication must come within this many frames of the previous one
 struct SequenceArgs {

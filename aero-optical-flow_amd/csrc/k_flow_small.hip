@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void k_flow_small_tagged(SmallArgs a, aof
 template <bool SUBPIXEL>
 __global__ __launch_bounds__(kThreads) void k_flow_resident(SmallArgs a, ResidentBox *box, aof_flow *host_record,
                                                             const uint8_t *frame_a, const uint8_t *frame_b, uint32_t served,
-                                                            uint32_t launch_no, uint64_t idle_ticks, uint64_t life_ticks)
+                                                            uint32_t launch_no, uint64_t idle_ticks, uint64_t life_ticks, int deaf)
 {
     __shared__ uint32_t s_req[3];   // request number (0 = leave), slot of the newest frame, buffers to fetch
     __shared__ aof_flow s_record;   // the call's flow record (the kernel's own copy goes to device memory)
@@ -380,9 +380,12 @@ __global__ __launch_bounds__(kThreads) void k_flow_resident(SmallArgs a, Residen
             unsigned long long word = 0;
             for (;;) {
                 word = __hip_atomic_load(&box->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one PCIe read
-                if (!(word & kResidentStopBit) && (uint32_t)word != served) { req = (uint32_t)word; break; }
+                // (deaf: fault injection of the tests -- the stop bit is ignored, the kernel neither serves nor leaves
+                //  when asked and goes on its idle / lifetime deadline only: aof_debug_resident_fault)
+                const bool stop = (word & kResidentStopBit) != 0;
+                if (!stop && (uint32_t)word != served) { req = (uint32_t)word; break; }
                 const uint64_t now = __builtin_amdgcn_s_memrealtime();
-                if ((word & kResidentStopBit) || now - idle_since > idle_ticks || now - born > life_ticks) break;
+                if ((stop && !deaf) || now - idle_since > idle_ticks || now - born > life_ticks) break;
                 __builtin_amdgcn_s_sleep(8);
             }
             if (req) {
@@ -458,10 +461,10 @@ bool flow_small_supported(const SmallArgs &a)
 
 int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_record, const uint8_t *frame_a,
                          const uint8_t *frame_b, uint32_t served, uint32_t launch_no, uint64_t idle_ticks,
-                         uint64_t life_ticks, void *stream)
+                         uint64_t life_ticks, bool deaf, void *stream)
 {
     if (a.l0.n_pairs != 1 || !flow_small_supported(a)) return (int)hipErrorInvalidValue;
-    void (*fn)(SmallArgs, ResidentBox *, aof_flow *, const uint8_t *, const uint8_t *, uint32_t, uint32_t, uint64_t, uint64_t) =
+    void (*fn)(SmallArgs, ResidentBox *, aof_flow *, const uint8_t *, const uint8_t *, uint32_t, uint32_t, uint64_t, uint64_t, int) =
         a.l0.subpixel ? k_flow_resident<true> : k_flow_resident<false>;
     const size_t lds = small_lds_bytes(a);
     if (lds > 48 * 1024) {
@@ -470,7 +473,7 @@ int launch_flow_resident(const SmallArgs &a, ResidentBox *box, aof_flow *host_re
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(fn, dim3(1), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a, box, host_record, frame_a, frame_b,
-                       served, launch_no, idle_ticks, life_ticks);
+                       served, launch_no, idle_ticks, life_ticks, deaf ? 1 : 0);
     return (int)hipGetLastError();
 }
 

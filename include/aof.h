@@ -232,6 +232,11 @@ typedef struct aof_stream_stats {
     char last_report[320];       /* text of the last fallback report, "" if none */
 } aof_stream_stats;
 int aof_stream_get_stats(const aof_ctx *ctx, aof_stream_stats *out);
+/* Fault injection for tests of the path above: resident kernel instances started from now on ignore the request to
+ * leave (deaf = 1; they still go on their own 50 ms / 200 ms deadlines), and the library waits stop_wait_us for a
+ * kernel to leave instead of one second (0 = the default).  Exercises the "kernel lost" branch: buffers abandoned,
+ * the context continues on fresh ones, aof_destroy leaks instead of freeing. */
+int aof_debug_resident_fault(aof_ctx *ctx, int deaf, uint32_t stop_wait_us);
 /* The streaming entry point replays a captured hipGraph per call (H2D frame, kernels, the result
  * written into pinned host memory; for frames of at most 64 KB served by the one-workgroup kernel:
  * that ONE kernel reading the pinned frames in place and publishing the record with a tag the host

@@ -1380,6 +1380,52 @@ def test_resident_kernel_serves_the_streaming_entry_point(aof, orc, synth, gpu_d
     assert "aof:" not in capfd.readouterr().err
 
 
+def test_a_resident_kernel_that_does_not_leave_costs_one_sample_and_never_a_hang(aof, orc, synth, gpu_device, capfd):
+    """Fault injection (aof_debug_resident_fault): the resident kernel ignores the request to leave and the library
+    waits 5 ms instead of a second.  Asked to step aside it is declared lost: one line on stderr, its box, stream and
+    pinned buffers abandoned.  The context then continues on fresh buffers -- the next frame starts a new sequence
+    (no flow, like the first frame), every later record equals the oracle's --, the counters say so, and aof_destroy
+    returns at once (it leaks instead of freeing under a kernel that may still run).  The zombie leaves by itself on
+    its 50 ms idle deadline; a new context afterwards works as if nothing had happened."""
+    import time
+    p = aof.px4flow_params(64, 64)
+    frames, _ = synth.make_sequence(64, 64, 16, 4, seed=61, max_step=3)
+    po = orc.params_from(p)
+    eng = aof.FlowEngine(p, 0)
+    eng.set_stream_resident(True)
+    eng.debug_resident_fault(True, 5000)
+    assert eng.stream_push(frames[0]) is None
+    for k in range(1, 5):
+        assert eng.stream_push(frames[k]).tobytes() == orc.flow_pair(po, frames[k - 1], frames[k])["flow"].tobytes()
+    assert eng.stream_resident_running()
+    t0 = time.perf_counter()
+    eng.set_stream_resident(False)                       # the deaf kernel does not leave within 5 ms
+    assert time.perf_counter() - t0 < 0.5
+    err = capfd.readouterr().err
+    assert "did not leave" in err and "abandoned" in err
+    st = eng.stream_stats()
+    assert st["resident_lost"] == 1 and st["resident_fallbacks"] == 0
+    assert eng.stream_push(frames[5]) is None            # fresh buffers: a new sequence starts
+    for k in range(6, 12):
+        assert eng.stream_push(frames[k]).tobytes() == orc.flow_pair(po, frames[k - 1], frames[k])["flow"].tobytes()
+    _, _, pair = eng.flow_pair_host(frames[2], frames[3])   # the other host entry point shares the rebuilt state
+    assert pair.tobytes() == orc.flow_pair(po, frames[2], frames[3])["flow"].tobytes()
+    eng.set_stream_resident(True)                        # the mode can be switched on again: a new box, a new (deaf) kernel
+    eng.debug_resident_fault(False, 0)
+    assert eng.stream_push(frames[12]).tobytes() == orc.flow_pair(po, frames[11], frames[12])["flow"].tobytes()
+    t0 = time.perf_counter()
+    eng.close()
+    assert time.perf_counter() - t0 < 1.5
+    assert "leaked, not freed" in capfd.readouterr().err
+    time.sleep(0.25)                                     # (every zombie has gone on its deadlines by now)
+    e2 = aof.FlowEngine(p, 0)
+    e2.set_stream_resident(True)
+    assert e2.stream_push(frames[0]) is None
+    assert e2.stream_push(frames[1]).tobytes() == orc.flow_pair(po, frames[0], frames[1])["flow"].tobytes()
+    e2.close()
+    assert "aof:" not in capfd.readouterr().err
+
+
 def test_streaming_path_follows_kernel_switches_mid_sequence(aof, orc, synth, gpu_device):
     """The streaming entry point replays captured hipGraphs: switching the kernel selection
     (aof_set_force_generic, aof_set_search_mode, aof_set_split_coarse) between two frames must
