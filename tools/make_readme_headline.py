@@ -31,7 +31,7 @@ def us(w, levels, resident):
 rf = c2["roofline"]
 txt = (f"Headline (`bench.py`, C2: 1 024 VGA pairs per launch, 8×8 SAD, ±4, exhaustive): **{c2['value']/1e6:.2f} M frame-pairs/s**, "
        f"K2 {rf['kernel_ms']*1e3:.1f} µs per launch = **{rf['frac']*100:.1f} % of the 8 TB/s HBM roofline** (whole step {rf['frac_step']*100:.1f} %; "
-       f"box to box the kernel takes 204–213 µs, `profiles/{rnd}_box_spread.txt`; it is VALU-bound at ≈ 80 % of its SAD-issue floor, which caps "
+       f"box to box the kernel takes 204–217 µs, `profiles/{rnd}_box_spread.txt`; it is VALU-bound at ≈ 80 % of its SAD-issue floor, which caps "
        f"the HBM fraction at 48 %), {two['value']/1e6:.2f} M with two batches in flight; "
        f"C3 (two-level pyramid + equalisation) {c3['value']/1e6:.2f} M pairs/s, {l3['value']/1e6:.2f} M = **{l3['roofline']['frac_step']*100:.1f} %** "
        f"(whole step) with two batches in flight; configs[3]'s per-GPU share of 128 pairs takes {share['ms_per_step']*1e3:.1f} µs per step against "
