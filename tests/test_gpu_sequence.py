@@ -225,3 +225,43 @@ def test_sequence_pipeline_scales_to_a_long_recording(aof, orc, synth, gpu_devic
     assert out["mavlink"] == wire
     assert np.all(np.diff(out["records"]["frame"].astype(np.int64)) > 0)
     eng.close()
+
+
+def test_sequence_entry_point_argument_handling(aof, gpu_device):
+    """aof_sequence_device straight through the C ABI: what it refuses (and with which code), and that refusing
+    leaves the context usable."""
+    import ctypes as C
+    import torch
+    p = aof.px4flow_params(64, 64)
+    eng = aof.FlowEngine(p, 0)
+    sp = aof.sequence_params(160, 120, 64, 64, FX, FY, 15, 1_000_000, 1, 100, 0)
+    n = 12
+    L = aof.sequence_layout(p, sp, n)
+    cam = torch.zeros((n, 120, 160), dtype=torch.uint8, device=gpu_device)
+    tt = torch.arange(n, dtype=torch.int64, device=gpu_device) * 13333
+    gy = torch.zeros((n, 4), dtype=torch.float32, device=gpu_device)
+    ws = torch.zeros(L.total_bytes + 256, dtype=torch.uint8, device=gpu_device)
+    stream = torch.cuda.current_stream().cuda_stream
+    call = aof.lib.aof_sequence_device
+    args = lambda **kw: [kw.get("ctx", eng._ctx), C.byref(kw.get("sp", sp)), kw.get("cam", cam.data_ptr()), 160 * 120, kw.get("n", n),
+                         kw.get("tt", tt.data_ptr()), kw.get("gy", gy.data_ptr()), kw.get("ws", ws.data_ptr()),
+                         kw.get("bytes", L.total_bytes), stream]
+    assert call(*args()) == 0
+    assert call(*args(ctx=None)) == -22
+    assert call(*args(cam=None)) == -22 and call(*args(tt=None)) == -22 and call(*args(ws=None)) == -22
+    assert call(*args(ws=ws.data_ptr() + 16)) == -22                     # 256-byte alignment
+    assert call(*args(bytes=L.total_bytes - 1)) == -28                   # -ENOSPC
+    assert call(*args(n=-1)) == -22
+    assert call(*args(n=0)) == 0                                         # nothing to do
+    assert call(*args(sp=aof.sequence_params(160, 120, 32, 32, FX, FY, 15, 1, 1, 100, 0))) == -22   # crop != the context's frame
+    assert call(*args(sp=aof.sequence_params(160, 120, 64, 64, 0.0, FY, 15, 1, 1, 100, 0))) == -22  # focal length must be positive
+    derot = aof.sequence_params(160, 120, 64, 64, FX, FY, 15, 1, 1, 100, 0, derotate=(4.5, 0.01))
+    Ld = aof.sequence_layout(p, derot, n)
+    wsd = torch.zeros(Ld.total_bytes, dtype=torch.uint8, device=gpu_device)
+    assert call(*args(sp=derot, gy=None, ws=wsd.data_ptr(), bytes=Ld.total_bytes)) == -22          # de-rotation needs the gyro
+    assert call(*args(sp=derot, ws=wsd.data_ptr(), bytes=Ld.total_bytes)) == 0
+    assert call(*args(gy=None)) == 0                                     # no gyro: zeros in the messages
+    torch.cuda.synchronize()
+    out = eng.sequence_outputs(sp, ws[:L.total_bytes], L, n)
+    assert len(out["records"]) >= 1 and out["records"][0]["frame"] == 0 and out["status"] == 0
+    eng.close()
