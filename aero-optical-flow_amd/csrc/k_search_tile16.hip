@@ -51,13 +51,15 @@ template <int NR, int STEP>
 __device__ __forceinline__ void sum_item(const uint8_t *s_prev, const uint8_t *s_cur, int W, int dyi, int bx, int xs,
                                          int first, u64 (&acc)[4], uint32_t &acc16, int delta = 0)
 {
-    // reference tile rows: 4 dwords at frame column 16*bx + 8
+    // reference tile rows: 4 dwords at frame column 16*bx + 8.  The prev rows are staged from column 8 on, so that a
+    // tile starts on a 16-byte boundary of the LDS image: ONE ds_read_b128 per row, neighbouring lanes on neighbouring
+    // 16 bytes (two 8-byte reads at a 16-byte lane stride hit every bank pair twice per pass)
     uint32_t ref[NR][4];
 #pragma unroll
     for (int i = 0; i < NR; i++) {
-        const uint2 *p = reinterpret_cast<const uint2 *>(s_prev + (size_t)(first + i * STEP) * W + 16 * bx + 8);
-        const uint2 lo = p[0], hi = p[1];
-        ref[i][0] = lo.x; ref[i][1] = lo.y; ref[i][2] = hi.x; ref[i][3] = hi.y;
+        uint4 q;
+        __builtin_memcpy(&q, s_prev + (size_t)(first + i * STEP) * W + 16 * bx, 16);   // (LDS: aligned; the probe reads global memory here)
+        ref[i][0] = q.x; ref[i][1] = q.y; ref[i][2] = q.z; ref[i][3] = q.w;
     }
     const uint8_t *win = s_cur + (size_t)(dyi + first) * W + xs;
 #pragma unroll
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
     const int sh = px & 15;                                       // floor-mod
     uint8_t *s_cur = smem + kPadBytes + (size_t)kLead * W;                // frame rows [16*by + py, +32) (REFINE: one more either side)
-    uint8_t *s_prev = smem + kPadBytes + (size_t)kCurRows * W;            // frame rows [16*by + 8, +16)
+    uint8_t *s_prev = smem + kPadBytes + (size_t)kCurRows * W;            // frame rows [16*by + 8, +16) from column 8 on (sum_item)
     uint32_t *s_best = reinterpret_cast<uint32_t *>(smem + kPadBytes + (size_t)(kCurRows + 16) * W);
     // Half-pixel refinement moves the grid origin to S+1 = 9: the same geometry on a frame whose
     // origin is moved by (1, 1) -- the flat copies start W+1 bytes later (byte-aligned loads);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     const int yc0 = 16 * by + py;                                 // moved-frame row of LDS cur row 0
     const bool rows_ok = yc0 >= 0 && yc0 + 32 <= H;               // wave-uniform: the whole block row
     const uint8_t *g_cur = a.cur + pair * a.pair_stride + org_off + (int64_t)yc0 * W + sh;
-    const uint8_t *g_prev = a.prev + pair * a.pair_stride + org_off + (int64_t)(16 * by + 8) * W;
+    const uint8_t *g_prev = a.prev + pair * a.pair_stride + org_off + (int64_t)(16 * by + 8) * W + 8;   // (8-byte aligned at best)
     int cur_chunks = rows_ok ? 32 * (W / 16) : 0;
     const int prev_chunks = 16 * (W / 16);
     // the displaced copy ends sh bytes past its last row: bytewise when that is the frame's end
@@ -215,9 +217,11 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         }
     }
     if (org == 0 && sh == 0)
-        for (int c = tid; c < prev_chunks; c += kThreads)
-            *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) =
-                *reinterpret_cast<const uint4 *>(g_prev + (size_t)c * 16);
+        for (int c = tid; c < prev_chunks; c += kThreads) {
+            uint4 v;
+            __builtin_memcpy(&v, g_prev + (size_t)c * 16, 16);
+            *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) = v;
+        }
     for (int b = tid; b < nx; b += kThreads) s_best[b] = 0xFFFFFFFFu;
     __syncthreads();
 
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const uint32_t *p =
-                reinterpret_cast<const uint32_t *>(s_prev + (size_t)(6 + r) * W + 16 * bx + 8 + 4);
+                reinterpret_cast<const uint32_t *>(s_prev + (size_t)(6 + r) * W + 16 * bx + 4);
             mid[r] = __builtin_amdgcn_alignbyte(p[1], p[0], 2);  // tile bytes 6..9
         }
         uint32_t diff = 0;
@@ -400,9 +404,8 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
                 uint32_t ref[kRows][4];
 #pragma unroll
                 for (int r = 0; r < kRows; r++) {
-                    const uint2 *p = reinterpret_cast<const uint2 *>(s_prev + (size_t)(kRows * part + r) * W + 16 * bx + 8);
-                    const uint2 lo = p[0], hi = p[1];
-                    ref[r][0] = lo.x; ref[r][1] = lo.y; ref[r][2] = hi.x; ref[r][3] = hi.y;
+                    const uint4 q = *reinterpret_cast<const uint4 *>(s_prev + (size_t)(kRows * part + r) * W + 16 * bx);
+                    ref[r][0] = q.x; ref[r][1] = q.y; ref[r][2] = q.z; ref[r][3] = q.w;
                 }
                 // ring row y of the slice: LDS row dyi + kRows part + y, bytes [xs + dxi - 1, + 18)
                 const int off0 = (dyi + kRows * part - 1) * W + (16 * bx + px - sh) + dxi - 1;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
         const int xf = 16 * bx + px, yc0 = 16 * by + py;
         uint32_t bound = 0xFFFFu;
         if (xf >= 0 && xf + 32 <= Wb && yc0 >= 0 && yc0 + 32 <= H)
-            bound = eval_item<kBoundRows, 16 / kBoundRows>(prev + (int64_t)(16 * by + 8) * W, cur + (int64_t)yc0 * W, W, dyi, bx, xf,
+            bound = eval_item<kBoundRows, 16 / kBoundRows>(prev + (int64_t)(16 * by + 8) * W + 8, cur + (int64_t)yc0 * W, W, dyi, bx, xf,
                                                            8 / kBoundRows, delta) >> 16;
         s_bound[blk][dyi] = (uint16_t)bound;
     }
