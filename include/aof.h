@@ -30,6 +30,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these are its exports */
+#endif
 
 #define AOF_VERSION 101 /* 0.1.1: aof_ws_layout.hints, aof_stream_stats, search mode ADAPTIVE */
 
@@ -370,6 +373,9 @@ int aof_kernel_ms(aof_ctx *ctx, int kernel_id, float *ms);
 int aof_profile_count(const aof_ctx *ctx, int kernel_id);
 int aof_profile_ms(aof_ctx *ctx, int kernel_id, int index, float *ms);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
