@@ -30,7 +30,9 @@ constexpr int kBoundRows = 2;  // tile rows summed for the lower bound of the pr
 // ADAPTIVE mode (the default of 16x16 contexts): the probe kernel below decides per pair.
 constexpr int kProbeThreads = 1024;        // a pair's ~1 200 probe items in two rounds
 constexpr int kProbeStride = 8;            // every eighth block in x and in y is probed (VGA-like grids: ~1.6 % of the blocks)
-constexpr int kProbeMaxBlocks = 128;       // sample blocks per pair at the most (the stride grows beyond that)
+constexpr int kProbeMaxBlocks = 128;       // sample blocks per pair at the most (the strides grow beyond that)
+// Blocks stride/2, stride/2 + stride, ... of an axis of n blocks.
+__host__ __device__ constexpr int probe_samples(int n, int stride) { return (n + stride - 1 - stride / 2) / stride; }
 // (thresholds from a same-box sweep over sensor noise 0 .. 40 LSB, profiles/r04_c5_adaptive_thresholds.txt: with
 //  6 x / 35 % the mode follows the faster of the two fixed modes within 5 % at every noise level but one, 8 %)
 constexpr uint32_t kFullOverBound = 6;     // a row can survive when its two-row bound <= this x the block's smallest bound
@@ -439,14 +441,14 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
 // residual is noise), and a row whose bound already exceeds the best complete SAD can be dropped.  More than
 // kMaxSurvivorsPct of them: hints[pair] = 0 (run the exhaustive scan), else 1.  A heuristic about SPEED
 // only: both branches of the search kernel write the same records.
-__global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, uint32_t *hints, int stride)
+__global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, uint32_t *hints, int stride_x, int stride_y)
 {
     __shared__ uint16_t s_bound[kProbeMaxBlocks][kSide + 1];
     __shared__ uint32_t s_tot[2];
     const int64_t pair = blockIdx.x;
     const int tid = threadIdx.x, W = a.w, nx = a.grid.nx, ny = a.grid.ny;
-    const int sx = (nx + stride - 1 - stride / 2) / stride, sy = (ny + stride - 1 - stride / 2) / stride;   // blocks stride/2, + stride, ...
-    const int nsamp = sx * sy;   // <= kProbeMaxBlocks (launcher)
+    const int sx = probe_samples(nx, stride_x), sy = probe_samples(ny, stride_y);   // blocks stride/2, + stride, ... per axis
+    const int nsamp = sx * sy;   // 1 .. kProbeMaxBlocks (launcher)
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * a.h));
     int px = 0, py = 0;
     if (a.pred) { px = a.pred[pair].pred_x; py = a.pred[pair].pred_y; }
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
     if (tid < 2) s_tot[tid] = 0;
     for (int s = tid; s < kSide * nsamp; s += kProbeThreads) {
         const int blk = s / kSide, dyi = s - blk * kSide;
-        const int by = (blk / sx) * stride + stride / 2, bx = (blk % sx) * stride + stride / 2;
+        const int by = (blk / sx) * stride_y + stride_y / 2, bx = (blk % sx) * stride_x + stride_x / 2;
         const int xf = 16 * bx + px, yc0 = 16 * by + py;
         uint32_t bound = 0xFFFFu;
         if (xf >= 0 && xf + 32 <= Wb && yc0 >= 0 && yc0 + 32 <= H)
@@ -516,12 +518,16 @@ int launch_search_tile16(const SearchArgs &a, void *stream)
     if (total > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
     if (a.prune == 2) {   // ADAPTIVE: judge every pair first (hints in the workspace), then the search decides per pair
         if (!a.hints) return (int)hipErrorInvalidValue;
-        int stride = kProbeStride;
-        auto samples = [&](int st) { return ((a.grid.nx + st - 1 - st / 2) / st) * ((a.grid.ny + st - 1 - st / 2) / st); };
-        while (samples(stride) > kProbeMaxBlocks) stride *= 2;
-        while (stride > 1 && samples(stride) == 0) stride /= 2;   // (small grids: every block)
+        // every kProbeStride-th block per axis; an axis with fewer blocks than that is sampled more densely (at least one
+        // block), and the strides grow -- the longer axis first -- until the sample fits the kernel's table
+        int stx = kProbeStride, sty = kProbeStride;
+        while (stx > 1 && probe_samples(a.grid.nx, stx) == 0) stx /= 2;
+        while (sty > 1 && probe_samples(a.grid.ny, sty) == 0) sty /= 2;
+        while (probe_samples(a.grid.nx, stx) * probe_samples(a.grid.ny, sty) > kProbeMaxBlocks) {
+            if (probe_samples(a.grid.nx, stx) >= probe_samples(a.grid.ny, sty)) stx *= 2; else sty *= 2;
+        }
         hipLaunchKernelGGL(k_tile16_probe, dim3((uint32_t)a.n_pairs), dim3(kProbeThreads), 0, static_cast<hipStream_t>(stream), a,
-                           a.hints, stride);
+                           a.hints, stx, sty);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }

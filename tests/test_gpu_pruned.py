@@ -214,3 +214,18 @@ def test_adaptive16_is_the_default_and_judges_every_pair_by_itself(aof, orc, syn
             torch.cuda.synchronize()
             assert torch.equal(b2, blocks) and torch.equal(f2, flows), (kw, mode)
         eng.close()
+
+
+@pytest.mark.parametrize("size", [(32, 5008), (48, 2000), (64, 64), (16 * 30, 48)])
+def test_adaptive16_probe_on_narrow_tall_and_tiny_grids(aof, orc, synth, gpu_device, size):
+    """The probe samples every 8th block per axis; an axis with fewer blocks is sampled more densely, and a long
+    one more sparsely so that the sample fits its table (a 1 x 311 grid once indexed past it).  All three modes
+    against the oracle on such geometries, clean and noisy."""
+    W, H = size
+    p = aof.default_params(W, H, tile=16, search=8, value_threshold=12000, min_valid=0)
+    if aof.check_params(p) != 0:
+        pytest.skip("geometry too small")
+    prevs, curs, _ = synth.make_batch(W, H, 2, 8, 9700 + W, noise=0)
+    rng = np.random.default_rng(5)
+    curs[1] = np.clip(curs[1].astype(np.int16) + rng.integers(-40, 41, curs[1].shape), 0, 255).astype(np.uint8)
+    pruned16_matches(aof, orc, p, prevs, curs, gpu_device)
