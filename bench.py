@@ -395,6 +395,56 @@ def bench_sequence(args, aof, device, rank, world, dist):
         dist.destroy_process_group()
 
 
+def being_profiled():
+    """A profiler is already wrapped around this process (its library is preloaded): no nested profiler runs."""
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):
+        return True
+    return "rocprof" in os.environ.get("LD_PRELOAD", "") or "roctracer" in os.environ.get("LD_PRELOAD", "")
+
+
+def live_traffic(args, n, search_flag):
+    """HBM bytes per launch of the dominant kernel and of the whole step, MEASURED now on this box: two child runs of
+    this same command (a handful of steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes,
+    only with --kernel-trace, the program itself after `--`, as /opt/skills/guides/MI355X_MICROARCH.md prescribes --
+    summarised with its gfx950 correction (FETCH_SIZE x 2 for wide coalesced reads) by tools/pmc_summary.py.
+    Returns (kernel_bytes, step_bytes, source) or None when the profiler is not usable here (the caller then falls
+    back to the committed summary of the same command)."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof) or being_profiled():
+        return None
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    if spec is None or not os.path.exists(os.path.join(ROOT, "tools", "pmc_summary.py")):
+        return None
+    pmc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pmc)
+    tmp = tempfile.mkdtemp(prefix="aof_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--pairs", str(args.pairs), "--steps", "4",
+             "--warmup", "1", "--settle-steps", "0", "--cpu-seconds", "0", "--traffic", "file", "--streams", "1", "--graph", "off",
+             "--noise", str(args.noise)] + search_flag
+    if args.brightness is not None:
+        child += ["--brightness", str(args.brightness)]
+    if args.max_shift is not None:
+        child += ["--max-shift", str(args.max_shift)]
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, counter), "--"] + child,
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
+        ent = pmc.summarise(tmp, args.workload, n)
+    except Exception:
+        ent = None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not ent:
+        return None
+    return ent["hbm_bytes_per_launch"], ent["step_bytes"], (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around two child runs of this "
+                                                           f"command (kernel {ent['kernel']}; FETCH_SIZE x 2 per the gfx950 correction)")
+
+
 def pmc_traffic(key, field="hbm_bytes_per_launch"):
     """HBM bytes per launch from the committed PMC summary of the same command (profiles/), and its source.
     field "step_bytes": all kernels of one step instead of the dominant kernel alone."""
@@ -504,6 +554,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the per-step gather even with ONE rank: rehearses the "
                          "N > 1 code path (RCCL, graph capture beside its watchdog thread) on a one-GPU box")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file"],
+                    help="roofline.traffic (HBM bytes per launch from the PMC counters): auto / live = measured in this run by two short "
+                         "child runs under rocprofv3 --pmc (one GPU only; falls back to the committed summary when the profiler is not "
+                         "usable or a profiler is already around this process), file = the committed summary of the same command")
     ap.add_argument("--configs3-pairs", type=int, default=1024,
                     help="N > 1: pairs of the strong-scaling shape every multi-GPU line also times (BASELINE configs[3]: "
                          "1024 pairs sharded over the GPUs, against the same pairs on one GPU); 0 = skip")
@@ -880,6 +934,17 @@ def main():
     # read from the committed summary of the same command under profiles/ (tools/collect_evidence.sh);
     # `traffic_source` names the file, or says that no summary exists for this workload and size.
     traffic, traffic_source = pmc_traffic(f"{args.workload}:{n}")
+    traffic_step = pmc_traffic(f"{args.workload}:{n}", "step_bytes")[0]
+    if args.traffic != "file" and rank == 0 and world == 1 and dist is None:
+        # (behind the timed region) measure it here and now; the committed summary stays the fallback
+        flag = [] if args.search == "auto" else ["--search", args.search]
+        if args.search == "auto" and eng.variant == "tile16_lds":
+            flag = ["--search", "adaptive"]   # (the default line also times the other modes: the probe run names the headline's)
+        live = live_traffic(args, n, flag)
+        if live:
+            traffic, traffic_step, traffic_source = live
+        elif args.traffic == "live":
+            traffic_source = "live measurement failed (rocprofv3 not usable here); " + str(traffic_source)
     step_ms = elapsed / args.steps * 1e3
     achieved_step = alg_bytes * n / (step_ms * 1e-3) / 1e9   # the whole step (every kernel + gaps), per GPU
 
@@ -906,7 +971,7 @@ def main():
                      "traffic_source": traffic_source,
                      # beyond-L2 bytes of ALL kernels of one step (same source): what to hold against the
                      # algorithmic bytes of a multi-kernel workload
-                     "traffic_step": pmc_traffic(f"{args.workload}:{n}", "step_bytes")[0],
+                     "traffic_step": traffic_step,
                      # the same algorithmic bytes over the WHOLE step (all kernels of the workload and
                      # the gaps between them): the figure to quote for multi-kernel workloads (c3, c5p)
                      "achieved_step": round(achieved_step, 1), "frac_step": round(achieved_step / HBM_PEAK_GBS, 4),

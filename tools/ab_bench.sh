@@ -7,7 +7,7 @@ mkdir -p $(dirname $out)
 for round in 1 2; do
     for lib in "$@"; do
         tag=$(basename $lib .so)
-        AOF_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload $wl --cpu-seconds 0 --steps 100 > ${out}_${tag}_$round.json 2> ${out}_${tag}_$round.err || { echo "$lib failed"; tail -3 ${out}_${tag}_$round.err; exit 1; }
+        AOF_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload $wl --cpu-seconds 0 --traffic file --steps 100 > ${out}_${tag}_$round.json 2> ${out}_${tag}_$round.err || { echo "$lib failed"; tail -3 ${out}_${tag}_$round.err; exit 1; }
     done
 done
 python - "$out" <<'PY'

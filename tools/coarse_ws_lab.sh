@@ -16,9 +16,9 @@ fi
 out=$2; mkdir -p $(dirname $out); : > $out
 line() { python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', j['value'], j['ms_per_step'], j['kernels_ms'], j['parity']['oracle_pairs_bit_exact'])"; }
 for round in 1 2; do
-  timeout -k 10 120 python3 bench.py --workload c3 --cpu-seconds 0 --steps 100 2>/dev/null | line shipped >> $out
+  timeout -k 10 120 python3 bench.py --workload c3 --cpu-seconds 0 --traffic file --steps 100 2>/dev/null | line shipped >> $out
   for lib in ab/ws*.so; do
-    AOF_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --workload c3 --cpu-seconds 0 --steps 100 2>/dev/null | line $(basename $lib .so) >> $out
+    AOF_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --workload c3 --cpu-seconds 0 --traffic file --steps 100 2>/dev/null | line $(basename $lib .so) >> $out
   done
 done
 cat $out

@@ -40,21 +40,21 @@ line() {   # tag, bench arguments...
 for wl in $WL; do
     case $wl in
     share)
-        line share_p1024 --cpu-seconds 0
-        line share_p1024_two_batches --streams 2 --cpu-seconds 0
-        line share_p128_one_batch_separate --pairs 128 --steps 200 --streams 1 --reduce separate --cpu-seconds 0
-        line share_p128_one_batch_fused --pairs 128 --steps 200 --streams 1 --reduce fused --cpu-seconds 0
-        line share_p128_two_batches_separate --pairs 128 --steps 200 --streams 2 --reduce separate --cpu-seconds 0
-        line share_p128 --pairs 128 --steps 200 --cpu-seconds 0
-        line share_p128_eager --pairs 128 --steps 200 --graph off --cpu-seconds 0
+        line share_p1024 --cpu-seconds 0 --traffic file
+        line share_p1024_two_batches --streams 2 --cpu-seconds 0 --traffic file
+        line share_p128_one_batch_separate --pairs 128 --steps 200 --streams 1 --reduce separate --cpu-seconds 0 --traffic file
+        line share_p128_one_batch_fused --pairs 128 --steps 200 --streams 1 --reduce fused --cpu-seconds 0 --traffic file
+        line share_p128_two_batches_separate --pairs 128 --steps 200 --streams 2 --reduce separate --cpu-seconds 0 --traffic file
+        line share_p128 --pairs 128 --steps 200 --cpu-seconds 0 --traffic file
+        line share_p128_eager --pairs 128 --steps 200 --graph off --cpu-seconds 0 --traffic file
         trace share_p128_one_batch_separate --pairs 128 --steps 200 --streams 1 --reduce separate
         trace share_p128 --pairs 128 --steps 200
         echo "share done";;
     lanes)
         for w2 in c2 c3 c2h c1b c5 c5h; do
-            line lanes_$w2 --workload $w2 $(args_of $w2) --streams 2 --reduce auto --cpu-seconds 0
+            line lanes_$w2 --workload $w2 $(args_of $w2) --streams 2 --reduce auto --cpu-seconds 0 --traffic file
         done
-        line lanes_c3_p512 --workload c3 --pairs 512 --streams 2 --cpu-seconds 0
+        line lanes_c3_p512 --workload c3 --pairs 512 --streams 2 --cpu-seconds 0 --traffic file
         echo "lanes done";;
     latency)
         cd $R && tools/stream_latency.sh > $O/stream_latency.txt 2> $O/stream_latency.err; cd /tmp

@@ -13,8 +13,9 @@ import os
 import sys
 
 
-def main():
-    root, workload, pairs, out_txt = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+def summarise(root, workload, pairs, out_txt=None):
+    """Returns the pmc_traffic.json entry of the passes under `root` (and writes the text summary / merges the entry into
+    pmc_traffic.json beside out_txt when that is given)."""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
@@ -42,8 +43,9 @@ def main():
             wr = 1024.0 * level0(acc[k]["WRITE_SIZE"])
             traffic[k] = (rd, wr)
             lines.append(f"    => HBM read {rd/1e6:.1f} MB (FETCH_SIZE x2, gfx950 correction) + write {wr/1e6:.1f} MB per launch")
-    open(out_txt, "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines))
+    if out_txt:
+        open(out_txt, "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines))
     # the level-0 search is the k_search kernel that moves the most bytes
     # (bench.py also runs the opt-in pruned search, template argument PRUNE = true: not the headline)
     names = [k for k in traffic if k.startswith("k_search") or k.startswith("k_flow")]
@@ -53,20 +55,22 @@ def main():
     if not names:   # workloads without a search kernel (ingest, derotate): the kernel that moves the most bytes
         names = list(traffic)
     search = sorted(names, key=lambda k: -sum(traffic[k]))
-    if search:
-        rd, wr = traffic[search[0]]
+    if not search:
+        return None
+    rd, wr = traffic[search[0]]
+    # every kernel of one step (the opt-in pruned variants bench.py also runs are not part of it);
+    # a kernel name that serves two launches per step (split coarse path) counts once, at its larger launch
+    step = {k: v for k, v in traffic.items() if not pruned(k)}
+    entry = {"kernel": search[0], "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
+             "step_bytes": int(sum(a + b for a, b in step.values())), "step_kernels": sorted(step),
+             "source": os.path.basename(out_txt) if out_txt else "live"}
+    if out_txt:
         path = os.path.join(os.path.dirname(os.path.abspath(out_txt)), "pmc_traffic.json")
         data = json.load(open(path)) if os.path.exists(path) else {}
-        # every kernel of one step (the opt-in pruned variants bench.py also runs are not part of it);
-        # a kernel name that serves two launches per step (split coarse path) counts once, at its larger launch
-        step = {k: v for k, v in traffic.items() if not pruned(k)}
-        data[f"{workload}:{pairs}"] = {"kernel": search[0], "hbm_bytes_per_launch": int(rd + wr),
-                                       "read_bytes": int(rd), "write_bytes": int(wr),
-                                       "step_bytes": int(sum(a + b for a, b in step.values())),
-                                       "step_kernels": sorted(step),
-                                       "source": os.path.basename(out_txt)}
+        data[f"{workload}:{pairs}"] = entry
         json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    return entry
 
 
 if __name__ == "__main__":
-    main()
+    summarise(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4])
