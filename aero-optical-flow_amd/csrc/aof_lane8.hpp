@@ -351,9 +351,10 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
             uint32_t rows[10][3];
 #pragma unroll
             for (int y = 0; y < 10; y++) {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_cur, ring, y * W, 0);
-                rows[y][0] = v.x; rows[y][1] = v.y;
-                rows[y][2] = __builtin_amdgcn_raw_buffer_load_b16(rs_cur, ring + 8, y * W, 0);
+                // ONE 16-byte load per ring row (10 bytes of it are used; the lines were touched a moment ago, and reads
+                // past the pair's frames return zero): half the load instructions of an 8-byte + a 2-byte load per row
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, ring, y * W, 0);
+                rows[y][0] = v.x; rows[y][1] = v.y; rows[y][2] = v.z & 0xFFFFu;
             }
             RefineState<2> st;
             st.init();
