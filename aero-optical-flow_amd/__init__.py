@@ -100,6 +100,15 @@ class StreamStats(C.Structure):
         return d
 
 
+class SearchStats(C.Structure):
+    """``aof_search_stats`` (include/aof.h): what the ADAPTIVE search mode of an 8x8 context has done so far."""
+    _fields_ = [("pruned_launches", C.c_uint64), ("exhaustive_launches", C.c_uint64), ("reports_read", C.c_uint64),
+                ("belief", C.c_int32), ("paying_pct", C.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class AofError(RuntimeError):
     def __init__(self, code, text):
         super().__init__(f"aof error {code}: {text}")
@@ -133,6 +142,7 @@ def _load():
         "aof_set_force_generic": (C.c_int, [VP, C.c_int]),
         "aof_set_search_mode": (C.c_int, [VP, C.c_int]),
         "aof_get_search_mode": (C.c_int, [VP]),
+        "aof_get_search_stats": (C.c_int, [VP, VP]),
         "aof_set_split_coarse": (C.c_int, [VP, C.c_int]),
         "aof_set_reduce_fusion": (C.c_int, [VP, C.c_int]),
         "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
@@ -331,6 +341,12 @@ class FlowEngine:
     @property
     def search_mode(self) -> int:
         return lib.aof_get_search_mode(self._ctx)
+
+    def search_stats(self) -> dict:
+        """Launch counters and current verdict of the ADAPTIVE 8x8 search (``aof_search_stats``)."""
+        st = SearchStats()
+        self._check(lib.aof_get_search_stats(self._ctx, C.byref(st)))
+        return st.as_dict()
 
     def set_split_coarse(self, on=True):
         """Two-level batches: run K1 / level-1 search / level-1 reduce as separate kernels (fills the

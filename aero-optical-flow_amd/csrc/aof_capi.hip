@@ -78,6 +78,14 @@ struct aof_ctx {
     // device -> host fault word (pinned, its own allocation): a kernel that gave up on a device-side wait
     // stores a non-zero code here; every entry point that enqueues work looks at it first
     uint32_t *h_fault;
+    // ADAPTIVE search of 8x8 contexts (run_search): what the pruned kernel's last reporting launch said, in
+    // pinned host words behind h_fault (same allocation), and what the context does with it
+    uint32_t *h_prune_slots;    // kPruneSlots words
+    uint32_t prune_launch_no;   // number of the last reporting launch (its low 16 bits tag the words)
+    uint32_t prune_expected;    // words that launch writes, 0 = none yet
+    int prune_belief;           // -1 nothing known yet, 0 pruning does not pay on this context's images, 1 it does
+    int prune_since_probe;      // exhaustive launches since the last look
+    aof_search_stats search_stats;
     uint32_t vote_deadline_ticks;   // finaliser waves of the in-launch reduction give up after this (100 MHz ticks)
     bool votes_captured;        // a captured graph holds an in-launch reduction: eager launches keep to K3
     // reduction inside the flat lane8 search (no K3 launch): the pairs' vote records, zero at rest
@@ -220,8 +228,8 @@ SearchArgs search_args(const aof_ctx *ctx, int level, const uint8_t *prev, const
     a.blocks = blocks; a.subdirs = p.subpixel ? subdirs : nullptr;
     a.pred = pred; a.sums = sums; a.level = level; a.n_pairs = n;
     a.hist_range = level_range(p, level);
-    // 0 exhaustive, 1 pruned, 2 adaptive (16x16: a probe kernel judges every pair first; the 8x8 pruned
-    // kernel decides per wave already, so both opt-in modes select it)
+    // 0 exhaustive, 1 pruned, 2 adaptive (16x16: a probe kernel judges every pair first; flat 8x8 launches:
+    // run_search decides per launch from what the context's previous launches reported)
     a.prune = ctx->search_mode;
     a.hints = nullptr;   // (16x16 searches: set from the workspace by enqueue_coarse / enqueue_fine)
     return a;
@@ -242,6 +250,46 @@ SearchKind search_kind(const aof_ctx *ctx, const SearchArgs &a)
     return SK_GENERIC;
 }
 
+// ADAPTIVE search of the flat 8x8 kernel: does THIS launch run the pruned kernel?  The exhaustive kernel is the
+// faster one wherever nothing can be pruned (the pruned kernel's own exhaustive path costs 6-10 % more: three waves
+// per SIMD, chunks walked in sequence), and a probe in front of every launch would cost more than it saves at
+// 0.2 us per pair -- so the context goes by what its PREVIOUS launches found: the pruned kernel reports how many
+// of its chunks left with "pruning pays" (PruneReport, plain stores into pinned memory that nobody waits for), the
+// context keeps using it while at least kPayingPct of them did, and otherwise runs the exhaustive kernel, with one
+// pruned launch in kProbeEvery to look again.  Speed only: every kernel writes the same records.
+constexpr uint32_t kPayingPct = 40;
+constexpr int kProbeEvery = 16;
+
+bool adaptive_lane8_prunes(aof_ctx *ctx, const SearchArgs &a)
+{
+    // half-pixel configurations: the pruned kernel loses even on clean translations (its refinement tail at three
+    // waves per SIMD); level-1 searches and small launches: too few chunks to carry a hint along
+    if (a.subpixel || a.level != 0 || !ctx->h_prune_slots || lane8_chunks(a) < kPruneMinChunks) return false;
+    if (ctx->prune_expected) {
+        const uint32_t tag = ctx->prune_launch_no & 0xFFFFu;
+        uint32_t arrived = 0, paying = 0, seen = 0;
+        for (uint32_t i = 0; i < ctx->prune_expected && i < (uint32_t)kPruneSlots; i++) {
+            const uint32_t w = __atomic_load_n(ctx->h_prune_slots + i, __ATOMIC_RELAXED);
+            if ((w >> 16) != tag) continue;
+            arrived++;
+            paying += (w >> 8) & 0xFFu;
+            seen += w & 0xFFu;
+        }
+        if (arrived * 4 >= ctx->prune_expected && seen) {   // (a launch still running has told enough after a quarter)
+            ctx->search_stats.paying_pct = (int32_t)(paying * 100u / seen);
+            ctx->prune_belief = paying * 100u >= seen * kPayingPct ? 1 : 0;
+            ctx->search_stats.belief = ctx->prune_belief;
+            ctx->search_stats.reports_read++;
+        }
+    }
+    if (ctx->prune_belief != 0) return true;
+    if (++ctx->prune_since_probe >= kProbeEvery) {
+        ctx->prune_since_probe = 0;
+        return true;
+    }
+    return false;
+}
+
 // Runs the level's search.  *reduced: the search kernel also wrote the pairs' flow records (grouped
 // lane8, flat lane8 with the reduction in its launch), no K3 follows.
 int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, hipStream_t s)
@@ -258,6 +306,28 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
         *reduced = true;
         break;
     case SK_LANE8: {
+        if (a.prune) {   // (the pruned kernel has no in-launch reduction)
+            PruneReport rep = {nullptr, 0, 1, 0};
+            if (ctx->search_mode == AOF_SEARCH_ADAPTIVE) {
+                if (!adaptive_lane8_prunes(ctx, a)) {
+                    a.prune = 0;
+                    ctx->search_stats.exhaustive_launches++;
+                } else {
+                    // a context that knows pruning pays starts every wave in the pruned code (optimistic, like
+                    // PRUNED); one that does not lets the first chunk of every wave run exhaustively and judge
+                    a.prune = ctx->prune_belief == 1 ? 1 : 2;
+                    if (++ctx->prune_launch_no % 0x10000u == 0) ctx->prune_launch_no++;   // (tag 0 = never written)
+                    rep.slots = ctx->h_prune_slots;
+                    rep.launch_no = ctx->prune_launch_no & 0xFFFFu;
+                    ctx->search_stats.pruned_launches++;
+                }
+            }
+            if (a.prune) {
+                rc = launch_search_lane8(a, s, nullptr, nullptr, &rep);
+                if (rep.slots) ctx->prune_expected = rep.expected;
+                break;
+            }
+        }
         // search + reduction in one launch when the context's vote memory can serve it; launches on
         // another stream than the last one wait for that one first (the records are shared)
         const VoteMem vm = {ctx->d_votes, kVoteStride, ctx->h_fault, ctx->vote_deadline_ticks};
@@ -557,19 +627,23 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
         const size_t bytes = (size_t)kVotePairs * kVoteStride * sizeof(uint32_t);
         if (hipMalloc((void **)&ctx->d_votes, bytes) != hipSuccess || hipMemset(ctx->d_votes, 0, bytes) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->votes_done, hipEventDisableTiming) != hipSuccess ||
-            hipHostMalloc((void **)&ctx->h_fault, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostMalloc((void **)&ctx->h_fault, 64 + kPruneSlots * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess) {
             aof_destroy(ctx);
             return -EIO;
         }
-        *ctx->h_fault = 0;
+        std::memset(ctx->h_fault, 0, 64 + kPruneSlots * sizeof(uint32_t));
+        ctx->h_prune_slots = ctx->h_fault + 16;
         ctx->votes_pairs = kVotePairs;
     }
     ctx->vote_deadline_ticks = kVoteDeadlineTicks;
     ctx->rstop_wait_s = 1.0;
     ctx->separate_reduce = true;   // the in-launch reduction is opt-in (aof_set_reduce_fusion)
-    // 16x16 tiles: exact pruning wherever the block row's own probe says it pays (include/aof.h)
-    ctx->search_mode = p->tile == 16 ? AOF_SEARCH_ADAPTIVE : AOF_SEARCH_EXHAUSTIVE;
+    // exact pruning wherever it pays (include/aof.h): 16x16 tiles by a probe per pair, 8x8 tiles by what the
+    // context's previous launches reported
+    ctx->search_mode = AOF_SEARCH_ADAPTIVE;
+    ctx->prune_belief = -1;
+    ctx->search_stats.belief = -1;
 
     *out = ctx;
     return 0;
@@ -626,6 +700,13 @@ void aof_destroy(aof_ctx *ctx)
 const char *aof_last_error(const aof_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
 int aof_get_search_mode(const aof_ctx *ctx) { return ctx ? ctx->search_mode : -EINVAL; }
+
+int aof_get_search_stats(const aof_ctx *ctx, aof_search_stats *out)
+{
+    if (!ctx || !out) return -EINVAL;
+    *out = ctx->search_stats;
+    return 0;
+}
 
 int aof_get_params(const aof_ctx *ctx, aof_params *out)
 {

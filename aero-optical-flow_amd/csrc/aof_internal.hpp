@@ -64,6 +64,18 @@ struct VoteMem {
     uint32_t deadline_ticks;   // finaliser waves give up after this many ticks of the 100 MHz counter
 };
 
+// What the pruned lane8 search tells the host about itself (the ADAPTIVE mode of 8x8 contexts, aof_capi.hip):
+// one workgroup in `stride` stores how many of its first wave's chunks left with "pruning pays" into a word of
+// pinned host memory: tag (low 16 bits of launch_no) << 16 | paying << 8 | chunks.  Plain stores, nobody waits
+// for them: the host reads whatever has arrived when it enqueues the next launch.  Speed only, never results.
+constexpr int kPruneSlots = 256;
+struct PruneReport {
+    uint32_t *slots;      // pinned, kPruneSlots words; nullptr = no report
+    uint32_t launch_no;
+    uint32_t stride;      // (filled by the launcher)
+    uint32_t expected;    // slots this launch writes (filled by the launcher)
+};
+
 // Everything one search launch needs; passed to the kernels by value.
 struct SearchArgs {
     const uint8_t *prev;       // level frames of the older image, pair i at +i*stride
@@ -82,7 +94,7 @@ struct SearchArgs {
     int32_t level;             // which sums column to use
     int64_t n_pairs;
     int32_t hist_range;        // R
-    int32_t prune;             // 0 exhaustive, 1 exact partial-distortion elimination (lane8, tile16), 2 adaptive (tile16: per pair, by hints)
+    int32_t prune;             // 0 exhaustive, 1 exact partial-distortion elimination (lane8, tile16), 2 adaptive (tile16: per pair, by hints; lane8: the first chunk of a wave runs exhaustively and judges)
     uint32_t *hints;           // tile16, adaptive: [n_pairs] written by its probe kernel (1 = pruning pays), workspace
     FastDiv div_nb, div_nx;    // lane8: filled by its launchers (item -> pair, block -> row)
 };
@@ -160,7 +172,11 @@ bool lane8_supported(const SearchArgs &a);
 // context's vote memory, the last wave of a pair writes its flow record); no K3 follows.
 bool lane8_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t capacity_pairs);
 int launch_search_lane8(const SearchArgs &a, void *stream, const FlowTail *tail = nullptr,
-                        const VoteMem *votes = nullptr);
+                        const VoteMem *votes = nullptr, PruneReport *report = nullptr);
+// 256-block chunks of the launch: the pruned kernel carries its hints from chunk to chunk of a workgroup and
+// needs a few thousand chunks before that pays (256 VGA pairs: +9 %, 512: +20 %, 1 024: +35 % on clean translations).
+int64_t lane8_chunks(const SearchArgs &a);
+constexpr int64_t kPruneMinChunks = 4096;
 // Grids of 8..256 blocks: a workgroup owns whole pairs and also writes their flow records (no K3).
 int lane8_group(const SearchArgs &a);  // pairs per workgroup, 0 = not applicable
 int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream);

@@ -84,6 +84,57 @@ __device__ __forceinline__ uint32_t exhaustive_search(const uint4 (&win)[16], co
     return best;
 }
 
+// The same scan for the ADAPTIVE mode of the pruned kernel: besides the best key it says how many of the nine dy
+// rows the pruned code would PROBABLY have dropped for the whole wave -- a row whose smallest SAD, scaled to the
+// 16 pixels of pruned_row's first test, lies above every needing lane's best.  A guess about speed only (it picks
+// the code that evaluates the wave's NEXT chunk); the keys are the exhaustive ones.
+constexpr int kJudgedRowsToPrune = 3;       // the next chunk prunes when at least this many rows look droppable
+constexpr uint32_t kPartialScaleQ10 = 410;  // 0.4: a row's smallest SAD over 64 pixels against what pruned_row's tests (16, then 32 pixels) see of it
+
+__device__ __forceinline__ uint32_t exhaustive_search_judged(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+                                                             int &droppable)
+{
+    u64 acc_lo[9], acc_hi[9];
+    uint32_t acc_8[9];
+#pragma unroll
+    for (int d = 0; d < 9; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)(d * 9 + 8); }
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const uint4 w = win[s];
+        const u64 p01 = pack64(w.x, w.y), p12 = pack64(w.y, w.z), p23 = pack64(w.z, w.w);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int d = s - r;
+            if (d < 0 || d >= 9) continue;
+            acc_lo[d] = qsad(p01, ref[r][0], acc_lo[d]);
+            acc_lo[d] = qsad(p12, ref[r][1], acc_lo[d]);
+            acc_hi[d] = qsad(p12, ref[r][0], acc_hi[d]);
+            acc_hi[d] = qsad(p23, ref[r][1], acc_hi[d]);
+            acc_8[d] = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], acc_8[d]);
+            acc_8[d] = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], acc_8[d]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t best = 0xFFFFFFFFu, row_key[9];
+#pragma unroll
+    for (int d = 0; d < 9; d++) {
+        const uint32_t base = (uint32_t)(d * 9);
+        const uint32_t l0 = (uint32_t)acc_lo[d], l1 = (uint32_t)(acc_lo[d] >> 32);
+        const uint32_t h0 = (uint32_t)acc_hi[d], h1 = (uint32_t)(acc_hi[d] >> 32);
+        const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
+        const uint32_t k2 = (l1 << 16) | (base + 2), k3 = (l1 & 0xFFFF0000u) | (base + 3);
+        const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
+        const uint32_t k6 = (h1 << 16) | (base + 6), k7 = (h1 & 0xFFFF0000u) | (base + 7);
+        row_key[d] = min(min(min(k0, k1), k2), min(min(min(k3, k4), k5), min(min(k6, k7), acc_8[d])));
+        best = min(best, row_key[d]);
+    }
+    droppable = 0;
+#pragma unroll
+    for (int d = 0; d < 9; d++)
+        droppable += __ballot(need && (((row_key[d] >> 16) * kPartialScaleQ10) >> 10) <= (best >> 16)) == 0 ? 1 : 0;
+    return best;
+}
+
 // One dy row (compile-time index D, so the window rows are plain registers) of the exact
 // pruned search: a partial SAD only grows, so when after two (then four) of the eight row pairs
 // no lane of the wave that still needs a result can beat or tie its best, the row is dropped for
@@ -310,7 +361,14 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
             if (__builtin_amdgcn_readfirstlane(prune_pays) == 0) {
                 // noise-dominated images: the previous chunk of this wave could drop (almost)
                 // nothing, and the exhaustive code is the faster way to evaluate everything
-                if (need) best = exhaustive_search<false>(win, ref, 0);
+                // ADAPTIVE: the wave's FIRST chunk comes here too (a pruned chunk that starts in the wrong row or drops
+                // nothing costs 1.4x the exhaustive one).  Every exhaustive chunk judges from its own SADs whether
+                // the next one should prune, and where it should start.
+                int droppable = 0;
+                best = exhaustive_search_judged(win, ref, need, droppable);
+                const int src = __ffsll((long long)needing) - 1;
+                start_row = (int)((uint32_t)__shfl((int)best, src, 64) & 0xFFFFu) / 9;
+                prune_pays = droppable >= kJudgedRowsToPrune;
             } else {
                 const int start = __builtin_amdgcn_readfirstlane(start_row);
                 const int dropped = pruned_search(win, ref, need, start, best);

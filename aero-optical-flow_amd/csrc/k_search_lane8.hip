@@ -44,24 +44,31 @@ constexpr int kThreads = 256;  // 64, 128 and 256 measure the same, 512 is 4 % s
 // frame) and each wave carries the dy row where its previous chunk matched.
 template <bool SUBPIXEL, bool PRUNE, bool EQ, bool VOTE = false>
 __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t items, uint32_t total_wgs, int spw,
-                                              const FlowTail *tail = nullptr, const VoteMem *votes = nullptr)
+                                              const FlowTail *tail = nullptr, const VoteMem *votes = nullptr,
+                                              const PruneReport *report = nullptr)
 {
     // consecutive workgroups = consecutive block rows of one pair: keep them on one XCD, whose L2
     // then serves the search rows that vertically adjacent blocks share
     const uint32_t wg = xcd_remap(blockIdx.x, total_wgs);
     const uint32_t nb = (uint32_t)a.grid.blocks();
-    int start_row = 4, prune_pays = 1;
+    // PRUNED starts optimistically in the centre row; ADAPTIVE lets the first chunk run exhaustively and judge
+    int start_row = 4, prune_pays = PRUNE && a.prune == 2 ? 0 : 1;
+    int chunks_seen = 0, chunks_paying = 0;   // (PRUNE: what this wave reports, below)
     for (int c = 0; c < spw; c++) {
         const uint32_t item0 = (wg * (uint32_t)spw + (uint32_t)c) * blockDim.x;   // < 2^31 (launcher)
         const uint32_t item = item0 + threadIdx.x;
         const bool live = item < items;
         if (!PRUNE && !VOTE && !live) return;
-        if (PRUNE && item0 >= items) return;   // whole workgroup past the end (uniform)
+        if (PRUNE && item0 >= items) break;    // whole workgroup past the end (uniform)
         const uint32_t pair = live ? fast_div(item, a.div_nb) : 0u;
         aof_block rec;
         rec.dx = 0; rec.dy = 0; rec.sad = AOF_SAD_SKIPPED;
         const int subdir = search_block<SUBPIXEL, PRUNE, EQ, VOTE && !SUBPIXEL && EQ>(a, pair, live ? item - __umul24(pair, nb) : 0u, item0, live,
                                                              rec, start_row, prune_pays);
+        if constexpr (PRUNE) {
+            chunks_seen++;
+            chunks_paying += __builtin_amdgcn_readfirstlane(prune_pays);
+        }
         if constexpr (VOTE) {
             // The reduction in the same launch: every lane stays until here and the wave adds its votes
             // to the records of the one or two pairs it covers (a pair has more than 64 blocks), without
@@ -90,6 +97,13 @@ __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t item
             if (first_item + 63 >= next_pair_at)   // (scalar) the wave reaches into the next pair
                 vote_and_arrive(*votes, a.hist_range, lead + 1, live2 && item2 >= next_pair_at, ok, bin_x, bin_y);
         }
+    }
+    if constexpr (PRUNE) {
+        // one workgroup in report->stride tells the host how its first wave fared (aof_internal.hpp: PruneReport)
+        if (report->slots && threadIdx.x == 0 && wg % report->stride == 0)
+            __hip_atomic_store(report->slots + wg / report->stride,
+                               (report->launch_no << 16) | ((uint32_t)chunks_paying << 8) | (uint32_t)chunks_seen,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -128,9 +142,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_flow_lane8_flat(SearchArgs a, u
 // the whole window live across a data-dependent loop: three waves per SIMD (168 VGPRs).
 template <bool SUBPIXEL>
 __global__ __launch_bounds__(kThreads, 3) void k_search_lane8_pruned(SearchArgs a, uint32_t items, uint32_t total_wgs,
-                                                                      int spw)
+                                                                      int spw, PruneReport report)
 {
-    search_chunks<SUBPIXEL, true, true>(a, items, total_wgs, spw);
+    search_chunks<SUBPIXEL, true, true>(a, items, total_wgs, spw, nullptr, nullptr, &report);
 }
 
 // Grouped mapping for grids of a few dozen blocks (the published sparse grid): a workgroup owns
@@ -242,8 +256,14 @@ bool lane8_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t ca
     return (a.n_pairs < per ? a.n_pairs : per) <= capacity_pairs;
 }
 
-int launch_search_lane8(const SearchArgs &a, void *stream, const FlowTail *tail, const VoteMem *votes)
+int64_t lane8_chunks(const SearchArgs &a)
 {
+    return (a.n_pairs * a.grid.blocks() + kThreads - 1) / kThreads;
+}
+
+int launch_search_lane8(const SearchArgs &a, void *stream, const FlowTail *tail, const VoteMem *votes, PruneReport *report)
+{
+    if (report) report->expected = 0;
     if (a.n_pairs == 0) return 0;
     if (a.subpixel && !a.subdirs) return (int)hipErrorInvalidValue;
     return for_slices(a, [&](const SearchArgs &s, int64_t done) {
@@ -262,19 +282,31 @@ int launch_search_lane8(const SearchArgs &a, void *stream, const FlowTail *tail,
                                static_cast<hipStream_t>(stream), s, (uint32_t)items, (uint32_t)wgs, t, *votes);
             return (int)hipGetLastError();
         }
-        const int threads = s.prune ? kThreads : flat_threads(items);
-        const int64_t chunks = (items + threads - 1) / threads;
-        // pruned search: consecutive chunks per workgroup so that all but the first inherit a start
-        // row; fewer when the launch is small and needs the workgroups for parallelism
-        int spw = 1;
-        if (s.prune) spw = chunks >= 4 * 4096 ? 4 : (chunks >= 2 * 4096 ? 2 : 1);
-        const int64_t wgs = (chunks + spw - 1) / spw;
+        const hipStream_t st = static_cast<hipStream_t>(stream);
+        if (s.prune) {
+            // consecutive chunks per workgroup, so that all but the first inherit start row and verdict -- as many as
+            // leave some 1 500 workgroups to the launch (1 024 VGA pairs: 8 chunks 6.29, 4: 6.14, 1: 5.13 M pairs/s;
+            // 256 pairs: 3 chunks 4.84, 8: 4.38; profiles/r04_p8_chunks_per_workgroup.txt)
+            const int64_t chunks = (items + kThreads - 1) / kThreads;
+            const int spw = (int)(chunks / 1536 < 1 ? 1 : (chunks / 1536 > 8 ? 8 : chunks / 1536));
+            const int64_t wgs = (chunks + spw - 1) / spw;
+            PruneReport rep = {nullptr, 0, 1, 0};
+            if (report && report->slots && done == 0) {   // (launches of more than 2^31 items: the first slice reports)
+                rep = *report;
+                rep.stride = (uint32_t)((wgs + kPruneSlots - 1) / kPruneSlots);
+                report->stride = rep.stride;
+                report->expected = (uint32_t)((wgs + rep.stride - 1) / rep.stride);
+            }
+            hipLaunchKernelGGL(s.subpixel ? k_search_lane8_pruned<true> : k_search_lane8_pruned<false>, dim3((uint32_t)wgs),
+                               dim3(kThreads), 0, st, s, (uint32_t)items, (uint32_t)wgs, spw, rep);
+            return (int)hipGetLastError();
+        }
+        const int threads = flat_threads(items);
+        const int64_t wgs = (items + threads - 1) / threads;
         void (*fn)(SearchArgs, uint32_t, uint32_t, int);
-        if (s.prune) fn = s.subpixel ? k_search_lane8_pruned<true> : k_search_lane8_pruned<false>;
-        else if (s.sums) fn = s.subpixel ? k_search_lane8<true, true> : k_search_lane8<false, true>;
+        if (s.sums) fn = s.subpixel ? k_search_lane8<true, true> : k_search_lane8<false, true>;
         else fn = s.subpixel ? k_search_lane8<true, false> : k_search_lane8<false, false>;
-        hipLaunchKernelGGL(fn, dim3((uint32_t)wgs), dim3(threads), 0, static_cast<hipStream_t>(stream), s,
-                           (uint32_t)items, (uint32_t)wgs, spw);
+        hipLaunchKernelGGL(fn, dim3((uint32_t)wgs), dim3(threads), 0, st, s, (uint32_t)items, (uint32_t)wgs, 1);
         return (int)hipGetLastError();
     });
 }

@@ -991,19 +991,18 @@ def main():
         out["configs3"] = configs3
 
     # ---- secondary, clearly separate: the OTHER search modes on the same batch ----
-    # (same records bit for bit.  8x8 tiles: the exhaustive scan is the headline -- a data-independent rate --
-    # and the exact-pruned mode rides beside it; 16x16 tiles: the exact-adaptive mode is the headline -- what a
-    # fresh context runs -- with the exhaustive scan and the always-pruned mode beside it.)
+    # (same records bit for bit.  The exact-adaptive mode is the headline -- what a fresh context runs -- with the
+    # exhaustive scan, a data-independent rate, and the always-pruned mode beside it.)
     # (the grouped small-grid lane8 kernel never prunes; the 16x16 kernel prunes per (dy row, block) item)
     mode_names = {aof.SEARCH_EXHAUSTIVE: "exhaustive", aof.SEARCH_PRUNED: "exact-pruned", aof.SEARCH_ADAPTIVE: "exact-adaptive"}
     head_mode = eng.search_mode
-    if eng.variant != "tile16_lds" and head_mode == aof.SEARCH_ADAPTIVE:
-        head_mode = aof.SEARCH_PRUNED     # (8x8: the pruned kernel decides per wave: the two names select it)
     out["config"]["search"] = mode_names[head_mode]
+    if eng.variant == "lane8" and head_mode == aof.SEARCH_ADAPTIVE:
+        # which kernel the context's launches ran (ADAPTIVE 8x8: decided per launch from the pruned kernel's own reports)
+        out["config"]["adaptive_search"] = eng.search_stats()
     pruned_available = (eng.variant == "lane8" and eng.nblocks(0) > 256) or eng.variant == "tile16_lds"
     if args.search == "auto" and pruned_available and not args.force_generic:
-        others = [m for m in ((aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED, aof.SEARCH_ADAPTIVE) if eng.variant == "tile16_lds"
-                              else (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED)) if m != head_mode]
+        others = [m for m in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED, aof.SEARCH_ADAPTIVE) if m != head_mode]
         ref_blocks = blocks.clone()
         for mode in others:
             eng.set_search_mode(mode)

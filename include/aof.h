@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these are its exports */
 #endif
 
-#define AOF_VERSION 101 /* 0.1.1: aof_ws_layout.hints, aof_stream_stats, search mode ADAPTIVE */
+#define AOF_VERSION 102 /* 0.1.2: ADAPTIVE is the default search mode of 8x8 contexts too, aof_search_stats */
 
 #define AOF_GRID_DENSE 0   /* origin = margin, step = tile */
 #define AOF_GRID_PX4FLOW 1 /* published sparse grid: num_blocks tiles per axis */
@@ -129,23 +129,39 @@ const char *aof_search_variant(const aof_ctx *ctx);
 /* Force the generic search kernel (tests compare the two device paths). */
 int aof_set_force_generic(aof_ctx *ctx, int on);
 /* Search strategy.  All return bit-identical records.
- * EXHAUSTIVE (default for 8x8 tiles): all candidates of every block are summed completely -- a
- *   data-independent rate, the one BASELINE's metric is quoted on.
+ * EXHAUSTIVE: all candidates of every block are summed completely -- a data-independent rate.
  * PRUNED: exact partial-distortion elimination (8x8 tiles on grids of more than 256 blocks, and
  *   16x16 tiles).  The dy rows are visited outwards from dy = 0; after a few of a row's tile rows a
  *   wave drops the row when no lane's partial SAD can still beat its best (a partial sum only grows).
  *   The rate then depends on the images: fast when blocks have a clear match near the centre, slower
  *   than the exhaustive search on noise (16x16: up to 1.5x; the 8x8 kernel falls back per wave).
- * ADAPTIVE (default for 16x16 tiles): PRUNED where it pays.  A small probe kernel in front of the search
- *   computes the two-row bounds of a sample of every pair's blocks (1.6 % of them) and the search runs a
- *   pair's block rows pruned when the bounds predict that few candidates survive, exhaustively otherwise
- *   (the verdicts live in the workspace, aof_ws_layout.hints); for 8x8 tiles the same as PRUNED (that
- *   kernel decides per wave already). */
+ * ADAPTIVE (the default): PRUNED where it pays.
+ *   16x16 tiles: a small probe kernel in front of the search computes the two-row bounds of a sample of every
+ *   pair's blocks (1.6 % of them) and the search runs a pair's block rows pruned when the bounds predict that few
+ *   candidates survive, exhaustively otherwise (the verdicts live in the workspace, aof_ws_layout.hints).
+ *   8x8 tiles (level-0 searches of at least 4 096 x 256 blocks per launch, no half-pixel step; everything else
+ *   runs EXHAUSTIVE): a probe per launch would cost more than it saves, so the CONTEXT learns from its own
+ *   launches.  The pruned kernel -- whose waves run a chunk of blocks exhaustively, judge from its SADs whether
+ *   rows could have been dropped, and prune the next chunks where they could -- reports the share of chunks that
+ *   pruned (plain stores into pinned host memory, read at the next enqueue, never waited for).  While that share
+ *   is at least 40 % the context keeps launching it (1 024 clean VGA translations: +30 % over EXHAUSTIVE);
+ *   otherwise it launches the exhaustive kernel, and the pruned one once in 16 launches to look again (noise of
+ *   +-16 LSB and more: -1 % against EXHAUSTIVE, where PRUNED alone loses 10 %).  A context's first launch and a
+ *   graph captured from it use whatever is known at that moment.  aof_get_search_stats tells what happened. */
 #define AOF_SEARCH_EXHAUSTIVE 0
 #define AOF_SEARCH_PRUNED 1
 #define AOF_SEARCH_ADAPTIVE 2
 int aof_set_search_mode(aof_ctx *ctx, int mode);
 int aof_get_search_mode(const aof_ctx *ctx);
+/* What the ADAPTIVE mode of an 8x8 context has done so far (diagnostics; tests assert on them). */
+typedef struct aof_search_stats {
+    uint64_t pruned_launches;     /* flat 8x8 searches run by the pruned kernel (it reports back) */
+    uint64_t exhaustive_launches; /* ... by the exhaustive kernel because the reports said pruning does not pay */
+    uint64_t reports_read;        /* launches' reports evaluated */
+    int32_t belief;               /* -1 nothing known yet, 0 pruning does not pay on this context's images, 1 it does */
+    int32_t paying_pct;           /* share of the last report's chunks that left with "pruning pays" */
+} aof_search_stats;
+int aof_get_search_stats(const aof_ctx *ctx, aof_search_stats *out);
 
 /* ---- the hot path, device-resident (batched) ----
  * d_prev/d_cur: device pointers, pair i at +i*pair_stride bytes, each frame

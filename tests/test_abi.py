@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(aof):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/aof.h but not exported"
     assert set(names) == set(aof.EXPORTS), "python binding and header disagree"
-    assert aof.lib.aof_version() == 101
+    assert aof.lib.aof_version() == 102
 
 
 def test_struct_layouts_match_header(aof, orc):

@@ -229,3 +229,145 @@ def test_adaptive16_probe_on_narrow_tall_and_tiny_grids(aof, orc, synth, gpu_dev
     rng = np.random.default_rng(5)
     curs[1] = np.clip(curs[1].astype(np.int16) + rng.integers(-40, 41, curs[1].shape), 0, 255).astype(np.uint8)
     pruned16_matches(aof, orc, p, prevs, curs, gpu_device)
+
+
+# ---- 8x8 tiles: AOF_SEARCH_ADAPTIVE, the default -- the context learns from its own launches which kernel to run ----
+
+def tiled(torch, arr, reps, device):
+    """`reps` copies of a small set of frames, interleaved, as one device batch."""
+    t = torch.from_numpy(arr).to(device)
+    return t.repeat((reps,) + (1,) * (t.dim() - 1)).contiguous()
+
+
+def replicas_equal(aof, blocks, flows, refs):
+    gb, gf = aof.blocks_view(blocks), aof.flows_view(flows)
+    k = len(refs)
+    for i in range(gb.shape[0]):
+        r = refs[i % k]
+        if gb[i].tobytes() != r["blocks"].tobytes() or gf[i].tobytes() != r["flow"].tobytes():
+            return i
+    return -1
+
+
+def test_adaptive8_is_the_default_and_learns_from_its_own_launches(aof, orc, synth, gpu_device):
+    """A fresh 8x8 context searches in AOF_SEARCH_ADAPTIVE.  Launches of at least 4 096 chunks of 256 blocks go to the
+    pruned kernel (whose waves judge, chunk by chunk, whether rows could be dropped) while the kernel's own reports
+    say that pruning pays, to the exhaustive kernel -- with one pruned launch in 16 to look again -- when they say
+    it does not.  Whatever it picks, the records are the oracle's, byte for byte."""
+    import torch
+    W, H, base, reps = 192, 160, 6, 480            # 23 x 19 = 437 blocks per pair, 2 880 pairs: 4 916 chunks
+    p = aof.default_params(W, H)
+    po = orc.params_from(p)
+    prevs, clean, _ = synth.make_batch(W, H, base, 4, 8100, noise=0)
+    rng = np.random.default_rng(5)
+    noisy = np.clip(clean.astype(np.int16) + rng.integers(-40, 41, clean.shape), 0, 255).astype(np.uint8)
+    tp = tiled(torch, prevs, reps, gpu_device)
+    batches = {"clean": (tiled(torch, clean, reps, gpu_device), [orc.flow_pair(po, prevs[i], clean[i]) for i in range(base)]),
+               "noisy": (tiled(torch, noisy, reps, gpu_device), [orc.flow_pair(po, prevs[i], noisy[i]) for i in range(base)])}
+    eng = aof.FlowEngine(p, 0)
+    assert eng.search_mode == aof.SEARCH_ADAPTIVE and eng.variant == "lane8"
+    assert eng.search_stats() == dict(pruned_launches=0, exhaustive_launches=0, reports_read=0, belief=-1, paying_pct=0)
+    ws = torch.zeros(aof.workspace_layout(p, base * reps).total_bytes, dtype=torch.uint8, device=gpu_device)
+
+    def call(kind):
+        tc, refs = batches[kind]
+        blocks, flows, _ = eng.flow_batch(tp, tc, workspace=ws)
+        torch.cuda.synchronize()
+        assert replicas_equal(aof, blocks, flows, refs) < 0, (kind, eng.search_stats())
+        return eng.search_stats()
+
+    for _ in range(3):
+        st = call("clean")
+    assert st["pruned_launches"] == 3 and st["exhaustive_launches"] == 0 and st["belief"] == 1, st
+    assert st["paying_pct"] >= 60, st
+    # noise: the first launch still prunes (and reports that it could not), the next ones run the exhaustive kernel,
+    # the 16th looks again
+    for _ in range(20):
+        st = call("noisy")
+    assert st["belief"] == 0 and st["paying_pct"] <= 10, st
+    assert st["pruned_launches"] == 3 + 1 + 1 and st["exhaustive_launches"] == 18, st
+    # clean again: found at the next look, at most 16 launches later
+    for _ in range(17):
+        st = call("clean")
+    assert st["belief"] == 1 and st["pruned_launches"] >= 3 + 2 + 2, st
+    before = st["pruned_launches"]
+    st = call("clean")
+    assert st["pruned_launches"] == before + 1, st
+    # without a host wait between the launches the reports arrive late or not at all: same records
+    for kind in ("noisy", "clean", "noisy"):
+        tc, refs = batches[kind]
+        for _ in range(5):
+            blocks, flows, _ = eng.flow_batch(tp, tc, workspace=ws)
+        torch.cuda.synchronize()
+        assert replicas_equal(aof, blocks, flows, refs) < 0, kind
+    eng.close()
+
+
+def test_adaptive8_leaves_small_launches_and_half_pixel_contexts_to_the_exhaustive_kernel(aof, orc, synth, gpu_device):
+    import torch
+    W, H = 192, 160
+    prevs, curs, _ = synth.make_batch(W, H, 4, 4, 8200, noise=1)
+    for kw, reps in ((dict(), 1), (dict(subpixel=1), 720)):
+        p = aof.default_params(W, H, **kw)
+        po = orc.params_from(p)
+        refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(4)]
+        eng = aof.FlowEngine(p, 0)
+        assert eng.search_mode == aof.SEARCH_ADAPTIVE
+        tp, tc = tiled(torch, prevs, reps, gpu_device), tiled(torch, curs, reps, gpu_device)
+        for _ in range(3):
+            blocks, flows, sub = eng.flow_batch(tp, tc)
+            torch.cuda.synchronize()
+        assert replicas_equal(aof, blocks, flows, refs) < 0
+        st = eng.search_stats()
+        assert st["pruned_launches"] == 0 and st["exhaustive_launches"] == 3 and st["belief"] == -1, st
+        eng.close()
+
+
+@pytest.mark.parametrize("case", ["ties", "flat_and_unrelated", "two_level", "mixed"])
+def test_adaptive8_judging_kernel_is_exact_on_hard_inputs(aof, orc, synth, gpu_device, case):
+    """The path the pruned kernel takes in the ADAPTIVE mode (first chunk of every wave exhaustively, with the verdict
+    about the next one from its SADs) on inputs with ties everywhere, flat halves, unrelated frames, a predictor and
+    saturating equalisation: large batches of interleaved replicas, so that consecutive chunks of a wave see different
+    kinds of pairs and the verdict flips back and forth."""
+    import torch
+    rng = np.random.default_rng(77)
+    W, H = 192, 160
+    kw = dict()
+    if case == "ties":
+        img = np.zeros((H, W), np.uint8); img[:, 0::2] = 200
+        img2 = np.zeros((H, W), np.uint8); img2[0::2, :] = 150
+        img3 = np.zeros((H, W), np.uint8); img3[0::4, 0::4] = 255
+        yy, xx = np.mgrid[0:H, 0:W]
+        chk = (((xx // 8 + yy // 8) % 2) * 255).astype(np.uint8)
+        prevs = np.stack([img, img2, img3, chk, chk])
+        curs = np.stack([img, img2, img3, chk, 255 - chk])
+        kw = dict(feature_threshold=0, value_threshold=70000)
+    elif case == "flat_and_unrelated":
+        prevs, curs, _ = synth.make_batch(W, H, 5, 4, 8300, noise=2)
+        prevs[0, : H // 2] = 90; curs[0, : H // 2] = 90                       # whole waves without a live block
+        curs[1] = rng.integers(0, 256, curs[1].shape, dtype=np.uint8)         # nothing can be pruned
+        curs[2] = prevs[2]                                                     # identical frames
+        prevs[3][:] = 17; curs[3][:] = 17                                      # no block passes the gate
+    elif case == "two_level":
+        kw = dict(pyramid_levels=2, mean_subtract=1)
+        prevs, curs, _ = synth.make_batch(W, H, 5, 9, 8400, noise=2, brightness=18)
+        curs[4] = np.clip(curs[4].astype(np.int16) + 90, 0, 255).astype(np.uint8)   # the equalisation saturates
+    else:
+        prevs, curs, _ = synth.make_batch(W, H, 6, 4, 8500, noise=0)
+        for i in (1, 3, 4):
+            curs[i] = np.clip(curs[i].astype(np.int16) + rng.integers(-30, 31, curs[i].shape), 0, 255).astype(np.uint8)
+    p = aof.default_params(W, H, **kw)
+    po = orc.params_from(p)
+    base = prevs.shape[0]
+    refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(base)]
+    reps = (4096 * 256 // 437 + base) // base + 1
+    tp, tc = tiled(torch, prevs, reps, gpu_device), tiled(torch, curs, reps, gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    for _ in range(3):   # (nothing known / what the first launch reported / what the second one did)
+        blocks, flows, _ = eng.flow_batch(tp, tc)
+        torch.cuda.synchronize()
+        bad = replicas_equal(aof, blocks, flows, refs)
+        assert bad < 0, (case, bad, eng.search_stats())
+    st = eng.search_stats()
+    assert st["pruned_launches"] >= 1 and st["reports_read"] >= 1, st
+    eng.close()
