@@ -16,6 +16,14 @@ __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
     return __builtin_amdgcn_qsad_pk_u16_u8(window, ref, acc);
 }
 __device__ __forceinline__ u64 pack64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | lo; }
+// Dwords 1 and 2 of a window row whose dwords (0, 1) and (2, 3) sit in two aligned register pairs: ONE v_pk_mov_b32
+// (pack64(w.y, w.z) compiles to it in the exhaustive kernels, but to two v_mov_b32 in the pruned rows).
+__device__ __forceinline__ u64 middle64(u64 p01, u64 p23)
+{
+    u64 r;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(p01), "v"(p23));
+    return r;
+}
 
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t x, uint32_t y)
@@ -84,95 +92,100 @@ __device__ __forceinline__ uint32_t exhaustive_search(const uint4 (&win)[16], co
     return best;
 }
 
-// The same scan for the ADAPTIVE mode of the pruned kernel: besides the best key it says how many of the nine dy
-// rows the pruned code would PROBABLY have dropped for the whole wave -- a row whose smallest SAD, scaled to the
-// 16 pixels of pruned_row's first test, lies above every needing lane's best.  A guess about speed only (it picks
-// the code that evaluates the wave's NEXT chunk); the keys are the exhaustive ones.
+// The exhaustive scan of the PRUNED kernel, dy row by dy row (five accumulator registers live instead of the 45 of
+// exhaustive_search: the kernel then needs 96 registers and runs five waves per SIMD, which is what hides the row
+// loads of its chunks -- on images that prune, half of a wave's time is waiting for them).  Besides the best key
+// it says how many of the nine dy rows the pruned code would PROBABLY have dropped for the whole wave: a row whose
+// smallest SAD, scaled to what pruned_row's tests see of it, lies above every needing lane's best.  A guess about
+// speed only (it picks the code that evaluates the wave's NEXT chunk); the keys are the exhaustive ones.
 constexpr int kJudgedRowsToPrune = 3;       // the next chunk prunes when at least this many rows look droppable
 constexpr uint32_t kPartialScaleQ10 = 410;  // 0.4: a row's smallest SAD over 64 pixels against what pruned_row's tests (16, then 32 pixels) see of it
 
-__device__ __forceinline__ uint32_t exhaustive_search_judged(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
-                                                             int &droppable)
+template <int D>
+__device__ __forceinline__ uint32_t full_row(const uint4 (&win)[16], const uint32_t (&ref)[8][2])
 {
-    u64 acc_lo[9], acc_hi[9];
-    uint32_t acc_8[9];
+    u64 alo = 0, ahi = 0;
+    uint32_t a8 = (uint32_t)(D * 9 + 8);
 #pragma unroll
-    for (int d = 0; d < 9; d++) { acc_lo[d] = 0; acc_hi[d] = 0; acc_8[d] = (uint32_t)(d * 9 + 8); }
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-        const uint4 w = win[s];
-        const u64 p01 = pack64(w.x, w.y), p12 = pack64(w.y, w.z), p23 = pack64(w.z, w.w);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int d = s - r;
-            if (d < 0 || d >= 9) continue;
-            acc_lo[d] = qsad(p01, ref[r][0], acc_lo[d]);
-            acc_lo[d] = qsad(p12, ref[r][1], acc_lo[d]);
-            acc_hi[d] = qsad(p12, ref[r][0], acc_hi[d]);
-            acc_hi[d] = qsad(p23, ref[r][1], acc_hi[d]);
-            acc_8[d] = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], acc_8[d]);
-            acc_8[d] = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], acc_8[d]);
-        }
+    for (int r = 0; r < 8; r++) {
+        const uint4 w = win[D + r];
+        const u64 p01 = pack64(w.x, w.y), p23 = pack64(w.z, w.w), p12 = middle64(p01, p23);
+        alo = qsad(p01, ref[r][0], alo);
+        ahi = qsad(p12, ref[r][0], ahi);
+        alo = qsad(p12, ref[r][1], alo);
+        ahi = qsad(p23, ref[r][1], ahi);
+        a8 = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], a8);
+        a8 = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], a8);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    uint32_t best = 0xFFFFFFFFu, row_key[9];
+    const uint32_t l0 = (uint32_t)alo, l1 = (uint32_t)(alo >> 32), h0 = (uint32_t)ahi, h1 = (uint32_t)(ahi >> 32);
+    const uint32_t base = (uint32_t)(D * 9);
+    const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
+    const uint32_t k2 = (l1 << 16) | (base + 2), k3 = (l1 & 0xFFFF0000u) | (base + 3);
+    const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
+    const uint32_t k6 = (h1 << 16) | (base + 6), k7 = (h1 & 0xFFFF0000u) | (base + 7);
+    return min(min(min(k0, k1), k2), min(min(min(k3, k4), k5), min(min(k6, k7), a8)));
+}
+
+__device__ __forceinline__ uint32_t exhaustive_search_judged(const uint4 (&win)[16], const uint32_t (&ref)[8][2],
+                                                             unsigned long long needing, int &droppable)
+{
+    uint32_t row_key[9];
+    for_rows<0, 8>([&](auto dc) {
+        constexpr int D = decltype(dc)::value;
+        row_key[D] = full_row<D>(win, ref);
+    });
+    uint32_t best = row_key[0];
 #pragma unroll
-    for (int d = 0; d < 9; d++) {
-        const uint32_t base = (uint32_t)(d * 9);
-        const uint32_t l0 = (uint32_t)acc_lo[d], l1 = (uint32_t)(acc_lo[d] >> 32);
-        const uint32_t h0 = (uint32_t)acc_hi[d], h1 = (uint32_t)(acc_hi[d] >> 32);
-        const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
-        const uint32_t k2 = (l1 << 16) | (base + 2), k3 = (l1 & 0xFFFF0000u) | (base + 3);
-        const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
-        const uint32_t k6 = (h1 << 16) | (base + 6), k7 = (h1 & 0xFFFF0000u) | (base + 7);
-        row_key[d] = min(min(min(k0, k1), k2), min(min(min(k3, k4), k5), min(min(k6, k7), acc_8[d])));
-        best = min(best, row_key[d]);
-    }
+    for (int d = 1; d < 9; d++) best = min(best, row_key[d]);
     droppable = 0;
 #pragma unroll
     for (int d = 0; d < 9; d++)
-        droppable += __ballot(need && (((row_key[d] >> 16) * kPartialScaleQ10) >> 10) <= (best >> 16)) == 0 ? 1 : 0;
+        droppable += (__ballot((((row_key[d] >> 16) * kPartialScaleQ10) >> 10) <= (best >> 16)) & needing) == 0 ? 1 : 0;
     return best;
 }
 
 // One dy row (compile-time index D, so the window rows are plain registers) of the exact
 // pruned search: a partial SAD only grows, so when after two (then four) of the eight row pairs
 // no lane of the wave that still needs a result can beat or tie its best, the row is dropped for
-// the whole wave.  Returns false when the row was dropped.
+// the whole wave.  Returns false when the row was dropped.  `needing` = ballot of the lanes that
+// need a result (the others carry whatever their registers hold and are masked out of the test).
+// A dropped row is the common case on images that prune at all (eight of nine rows under a global
+// translation), so the test is kept short: ONE accumulator set (64 pixels x 255 fit a u16 field),
+// the minimum over the nine offsets as four packed minima and one min, the ballot and its mask in
+// scalar registers -- about 9 instructions behind the row's first 12 SAD instructions.
 template <int D>
-__device__ __forceinline__ bool pruned_row(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+__device__ __forceinline__ bool pruned_row(const uint4 (&win)[16], const uint32_t (&ref)[8][2], unsigned long long needing,
                                            uint32_t &best)
 {
-    u64 alo[2] = {0, 0}, ahi[2] = {0, 0};
-    uint32_t a8[2] = {(uint32_t)(D * 9 + 8), 0u};
-    auto row_pair = [&](int r, int set) {
+    u64 alo = 0, ahi = 0;
+    uint32_t a8 = (uint32_t)(D * 9 + 8);
+    auto row_pair = [&](int r) {
         const uint4 w = win[D + r];
-        const u64 p01 = pack64(w.x, w.y), p12 = pack64(w.y, w.z), p23 = pack64(w.z, w.w);
-        alo[set] = qsad(p01, ref[r][0], alo[set]);
-        ahi[set] = qsad(p12, ref[r][0], ahi[set]);
-        alo[set] = qsad(p12, ref[r][1], alo[set]);
-        ahi[set] = qsad(p23, ref[r][1], ahi[set]);
-        a8[set] = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], a8[set]);
-        a8[set] = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], a8[set]);
+        const u64 p01 = pack64(w.x, w.y), p23 = pack64(w.z, w.w), p12 = middle64(p01, p23);
+        alo = qsad(p01, ref[r][0], alo);
+        ahi = qsad(p12, ref[r][0], ahi);
+        alo = qsad(p12, ref[r][1], alo);
+        ahi = qsad(p23, ref[r][1], ahi);
+        a8 = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], a8);
+        a8 = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], a8);
     };
-    auto partial_min = [&]() -> uint32_t {  // <= 32 pixels per field: no carry between the u16 fields
-        const uint32_t s0 = (uint32_t)alo[0] + (uint32_t)alo[1], s1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
-        const uint32_t s2 = (uint32_t)ahi[0] + (uint32_t)ahi[1], s3 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
-        const uint32_t m = pk_min_u16(pk_min_u16(s0, s1), pk_min_u16(s2, s3));
-        return min(min(m & 0xFFFFu, m >> 16), (a8[0] + a8[1]) >> 16);
+    auto nobody_can_win = [&]() -> bool {
+        const uint32_t m = pk_min_u16(pk_min_u16((uint32_t)alo, (uint32_t)(alo >> 32)), pk_min_u16((uint32_t)ahi, (uint32_t)(ahi >> 32)));
+        const uint32_t m9 = pk_min_u16(m, a8 | 0xFFFFu);   // offset 8's sum rides in a8's upper half
+        const uint32_t smallest = min(m9 & 0xFFFFu, m9 >> 16);
+        return (__ballot(smallest <= (best >> 16)) & needing) == 0;
     };
-    row_pair(0, 0);
-    row_pair(4, 1);
-    if (__ballot(need && partial_min() <= (best >> 16)) == 0) return false;
-    row_pair(2, 0);
-    row_pair(6, 1);
-    if (__ballot(need && partial_min() <= (best >> 16)) == 0) return false;
-    row_pair(1, 1);
-    row_pair(3, 0);
-    row_pair(5, 1);
-    row_pair(7, 0);
-    const uint32_t l0 = (uint32_t)alo[0] + (uint32_t)alo[1], l1 = (uint32_t)(alo[0] >> 32) + (uint32_t)(alo[1] >> 32);
-    const uint32_t h0 = (uint32_t)ahi[0] + (uint32_t)ahi[1], h1 = (uint32_t)(ahi[0] >> 32) + (uint32_t)(ahi[1] >> 32);
+    row_pair(0);
+    row_pair(4);
+    if (nobody_can_win()) return false;
+    row_pair(2);
+    row_pair(6);
+    if (nobody_can_win()) return false;
+    row_pair(1);
+    row_pair(3);
+    row_pair(5);
+    row_pair(7);
+    const uint32_t l0 = (uint32_t)alo, l1 = (uint32_t)(alo >> 32), h0 = (uint32_t)ahi, h1 = (uint32_t)(ahi >> 32);
     const uint32_t base = (uint32_t)(D * 9);
     const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
     const uint32_t k2 = (l1 << 16) | (base + 2), k3 = (l1 & 0xFFFF0000u) | (base + 3);
@@ -180,7 +193,7 @@ __device__ __forceinline__ bool pruned_row(const uint4 (&win)[16], const uint32_
     const uint32_t k6 = (h1 << 16) | (base + 6), k7 = (h1 & 0xFFFF0000u) | (base + 7);
     best = min(best, min(min(k0, k1), k2));
     best = min(best, min(min(k3, k4), k5));
-    best = min(best, min(min(k6, k7), a8[0] + a8[1]));
+    best = min(best, min(min(k6, k7), a8));
     return true;
 }
 
@@ -198,7 +211,7 @@ constexpr int visit_order(int start, int k)
 // All nine rows from a compile-time start row: straight-line code, every window row a plain
 // register (a run-time row index would push the 64-register window into scratch).
 template <int START, int K = 0>
-__device__ __forceinline__ int pruned_from(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+__device__ __forceinline__ int pruned_from(const uint4 (&win)[16], const uint32_t (&ref)[8][2], unsigned long long need,
                                            uint32_t &best)
 {
     const int dropped = pruned_row<visit_order(START, K)>(win, ref, need, best) ? 0 : 1;
@@ -208,7 +221,7 @@ __device__ __forceinline__ int pruned_from(const uint4 (&win)[16], const uint32_
 
 // The nine dy rows in the order start, start-1, start+1, ... (start is wave-uniform): one
 // specialised copy of the row sequence per start row; returns how many rows were dropped.
-__device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint32_t (&ref)[8][2], bool need,
+__device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint32_t (&ref)[8][2], unsigned long long need,
                                              int start, uint32_t &best)
 {
     switch (start) {
@@ -365,13 +378,13 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
                 // nothing costs 1.4x the exhaustive one).  Every exhaustive chunk judges from its own SADs whether
                 // the next one should prune, and where it should start.
                 int droppable = 0;
-                best = exhaustive_search_judged(win, ref, need, droppable);
+                best = exhaustive_search_judged(win, ref, needing, droppable);
                 const int src = __ffsll((long long)needing) - 1;
                 start_row = (int)((uint32_t)__shfl((int)best, src, 64) & 0xFFFFu) / 9;
                 prune_pays = droppable >= kJudgedRowsToPrune;
             } else {
                 const int start = __builtin_amdgcn_readfirstlane(start_row);
-                const int dropped = pruned_search(win, ref, need, start, best);
+                const int dropped = pruned_search(win, ref, needing, start, best);
                 // the wave's next chunk starts where its first live block matched
                 const int src = __ffsll((long long)needing) - 1;
                 start_row = (int)((uint32_t)__shfl((int)best, src, 64) & 0xFFFFu) / 9;

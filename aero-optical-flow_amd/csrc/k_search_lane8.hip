@@ -138,10 +138,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_flow_lane8_flat(SearchArgs a, u
     search_chunks<SUBPIXEL, false, EQ, true>(a, items, search_wgs, 1, &tail, &votes);
 }
 
-// The pruned search holds both code paths (pruned rows and the exhaustive fallback) and keeps
-// the whole window live across a data-dependent loop: three waves per SIMD (168 VGPRs).
+// The pruned search holds both code paths (pruned rows and the exhaustive scan that judges) and keeps the whole
+// window live across a data-dependent loop.  Both work dy row by dy row on five accumulator registers, so the
+// kernel stays within the 128 VGPRs of four waves per SIMD (122; 148 and three waves while its exhaustive path
+// carried the 45 accumulators of exhaustive_search).
 template <bool SUBPIXEL>
-__global__ __launch_bounds__(kThreads, 3) void k_search_lane8_pruned(SearchArgs a, uint32_t items, uint32_t total_wgs,
+__global__ __launch_bounds__(kThreads, 4) void k_search_lane8_pruned(SearchArgs a, uint32_t items, uint32_t total_wgs,
                                                                       int spw, PruneReport report)
 {
     search_chunks<SUBPIXEL, true, true>(a, items, total_wgs, spw, nullptr, nullptr, &report);
