@@ -150,6 +150,43 @@ __device__ __forceinline__ void wave_vote2(uint32_t *hist_x, uint32_t *hist_y, i
     wave_vote(hist_y, bin_y, active);
 }
 
+// The same with a small weight per lane (0 = no vote, at most 4: a lane that speaks for up to four consecutive records
+// which agree).  The weights of the lanes that share a bin are summed through the ballots of "weight == w" (scalar
+// popcounts), so a weighted vote costs what a plain one does.  Integer adds: the histograms do not depend on the grouping.
+__device__ __forceinline__ void wave_vote_weighted(uint32_t *hist, int bin, int weight, unsigned long long m1, unsigned long long m2,
+                                                   unsigned long long m3, unsigned long long m4)
+{
+    unsigned long long todo = m1 | m2 | m3 | m4;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bin, leader, 64);
+        const unsigned long long same = __ballot(weight != 0 && bin == b) & todo;
+        const uint32_t total = (uint32_t)(__popcll(same & m1) + 2 * __popcll(same & m2) + 3 * __popcll(same & m3) + 4 * __popcll(same & m4));
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], total);
+        todo &= ~same;
+    }
+}
+
+// key = bin_x | bin_y << 16.  Must be called by every lane of the wave.
+__device__ __forceinline__ void wave_vote2_weighted(uint32_t *hist_x, uint32_t *hist_y, int key, int weight)
+{
+    const unsigned long long m1 = __ballot(weight == 1), m2 = __ballot(weight == 2), m3 = __ballot(weight == 3), m4 = __ballot(weight == 4);
+    const unsigned long long todo = m1 | m2 | m3 | m4;
+    if (todo == 0) return;
+    const int leader = __ffsll((long long)todo) - 1;
+    const int k = __shfl(key, leader, 64);
+    if ((__ballot(weight != 0 && key == k) & todo) == todo) {   // (wave-uniform) one global motion: one leader, two adds
+        if ((int)(threadIdx.x & 63) == leader) {
+            const uint32_t total = (uint32_t)(__popcll(m1) + 2 * __popcll(m2) + 3 * __popcll(m3) + 4 * __popcll(m4));
+            atomicAdd(&hist_x[k & 0xFFFF], total);
+            atomicAdd(&hist_y[k >> 16], total);
+        }
+        return;
+    }
+    wave_vote_weighted(hist_x, key & 0xFFFF, weight, m1, m2, m3, m4);
+    wave_vote_weighted(hist_y, key >> 16, weight, m1, m2, m3, m4);
+}
+
 // Bijective XCD-aware remap of a 1-D grid (workgroups b and b+8 share an XCD's
 // L2 under round-robin placement): XCD k gets one contiguous chunk of logical
 // ids, so consecutive block rows of one frame pair are served by the same L2.
