@@ -264,7 +264,7 @@ bool adaptive_lane8_prunes(aof_ctx *ctx, const SearchArgs &a)
 {
     // half-pixel configurations: the pruned kernel loses even on clean translations (its refinement tail at three
     // waves per SIMD); level-1 searches and small launches: too few chunks to carry a hint along
-    if (a.subpixel || a.level != 0 || !ctx->h_prune_slots || lane8_chunks(a) < kPruneMinChunks) return false;
+    if (a.level != 0 || !ctx->h_prune_slots || lane8_chunks(a) < kPruneMinChunks) return false;
     if (ctx->prune_expected) {
         const uint32_t tag = ctx->prune_launch_no & 0xFFFFu;
         uint32_t arrived = 0, paying = 0, seen = 0;

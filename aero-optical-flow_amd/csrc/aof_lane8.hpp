@@ -237,6 +237,36 @@ __device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint3
     }
 }
 
+// Half-pixel refinement with the ring taken out of the 16x16 window in registers: rows udy-1 .. udy+8 (udy wave-uniform,
+// 1..7: compile-time inside the switch), bytes o .. o+9 (o per lane, 0..6: a v_alignbyte per dword).  Row by row, so
+// that nothing but the window and the refinement's own state is live (the kernel stays at four waves per SIMD).
+template <int UDY>
+__device__ __forceinline__ void refine_rows_from_window(const uint4 (&win)[16], int o, const uint32_t (&ref)[8][2], RefineState<2> &st)
+{
+    const bool upper = o >= 4;   // (v_alignbyte shifts by o & 3)
+    for_rows<-1, 8>([&](auto yc) {
+        constexpr int Y = decltype(yc)::value;
+        const uint4 w = win[UDY + Y];
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(w.y, w.x, (uint32_t)o), a1 = __builtin_amdgcn_alignbyte(w.z, w.y, (uint32_t)o);
+        const uint32_t a2 = __builtin_amdgcn_alignbyte(w.w, w.z, (uint32_t)o), a3 = __builtin_amdgcn_alignbyte(0u, w.w, (uint32_t)o);
+        const uint32_t d[3] = {upper ? a1 : a0, upper ? a2 : a1, (upper ? a3 : a2) & 0xFFFFu};
+        st.template row<Y>(d, ref);
+    });
+}
+
+__device__ __forceinline__ void refine_from_window(const uint4 (&win)[16], int udy, int o, const uint32_t (&ref)[8][2], RefineState<2> &st)
+{
+    switch (udy) {
+    case 1: refine_rows_from_window<1>(win, o, ref, st); break;
+    case 2: refine_rows_from_window<2>(win, o, ref, st); break;
+    case 3: refine_rows_from_window<3>(win, o, ref, st); break;
+    case 4: refine_rows_from_window<4>(win, o, ref, st); break;
+    case 5: refine_rows_from_window<5>(win, o, ref, st); break;
+    case 6: refine_rows_from_window<6>(win, o, ref, st); break;
+    default: refine_rows_from_window<7>(win, o, ref, st); break;
+    }
+}
+
 // One block: record (and direction) written to global memory and returned for the votes.
 // Returns the half-pixel direction (8 = none).  PRUNE: the wave-uniform exact pruned search;
 // start_row / prune_pays are the wave's hints carried from its previous chunk of blocks (every
@@ -420,6 +450,38 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
         if ((uint32_t)rec.sad < (uint32_t)a.value_threshold) {
             const uint32_t ring = off_cur + (uint32_t)((idx / 9 - 1) * W + (idx % 9 - 1));
             uint32_t rows[10][3];
+            if constexpr (PRUNE) {
+                // The pruned kernel is latency-bound where it prunes, and a second round of row loads per chunk doubles
+                // what the refinement costs it (135 against 66 us per 1 024 VGA pairs).  A best match that is not on the
+                // window's rim has its whole ring IN the window registers: the wave's refining lanes that share the first
+                // one's dy (under a global motion: all of them) cut their ten rows out of them -- the row index is then
+                // wave-uniform, i.e. compile-time inside a seven-way switch, and the byte offset is a per-lane
+                // v_alignbyte --; the window is equalised already.  The other lanes load their ring.
+                const int dyi = idx / 9, dxi = idx - 9 * dyi;
+                const unsigned long long refining = __ballot(true);
+                const int udy = __builtin_amdgcn_readlane(dyi, __ffsll((long long)refining) - 1);
+                const bool have_ring = dyi == udy && udy >= 1 && udy <= 7 && dxi >= 1 && dxi <= 7;
+                RefineState<2> st;
+                st.init();
+                if (have_ring) refine_from_window(win, udy, dxi - 1, ref, st);
+                if (!have_ring) {
+#pragma unroll
+                    for (int y = 0; y < 10; y++) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, ring, y * W, 0);
+                        rows[y][0] = v.x; rows[y][1] = v.y; rows[y][2] = v.z & 0xFFFFu;
+                    }
+                    for_rows<-1, 8>([&](auto yc) {
+                        constexpr int Y = decltype(yc)::value;
+                        uint32_t d[3] = {rows[Y + 1][0], rows[Y + 1][1], rows[Y + 1][2]};
+                        if (delta != 0) {
+#pragma unroll
+                            for (int q = 0; q < 3; q++) d[q] = sat_add_u8x4(d[q], delta);
+                        }
+                        st.template row<Y>(d, ref);
+                    });
+                }
+                subdir = st.direction(rec.sad);
+            } else {
 #pragma unroll
             for (int y = 0; y < 10; y++) {
                 // ONE 16-byte load per ring row (10 bytes of it are used; the lines were touched a moment ago, and reads
@@ -439,6 +501,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
                 st.template row<Y>(d, ref);
             });
             subdir = st.direction(rec.sad);
+            }
         }
         a.subdirs[item] = (uint8_t)subdir;
     }

@@ -101,6 +101,52 @@ def test_pruned_fuzz(aof, orc, synth, gpu_device, seed):
     both_modes_match_oracle(aof, orc, p, prevs, curs, gpu_device)
 
 
+def half_pixel_modes_match_oracle(aof, orc, p, prevs, curs, device):
+    """Records, directions and flow of the exhaustive and the pruned 8x8 kernel against the oracle."""
+    import torch
+    po = orc.params_from(p)
+    refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(prevs.shape[0])]
+    tp, tc = torch.from_numpy(prevs).to(device), torch.from_numpy(curs).to(device)
+    for mode in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED):
+        eng = aof.FlowEngine(p, 0)
+        eng.set_search_mode(mode)
+        sub = torch.full((prevs.shape[0], eng.nblocks(0)), 0x77, dtype=torch.uint8, device=device)
+        for _ in range(2):
+            blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+        torch.cuda.synchronize()
+        gb, gf, gs = aof.blocks_view(blocks), aof.flows_view(flows), sub.cpu().numpy()
+        for i, r in enumerate(refs):
+            assert gb[i].tobytes() == r["blocks"].tobytes(), (mode, i)
+            assert gs[i].tobytes() == r["subdirs"].tobytes(), (mode, i, np.flatnonzero(gs[i] != r["subdirs"])[:8])
+            assert gf[i].tobytes() == r["flow"].tobytes(), (mode, i)
+        eng.close()
+
+
+def test_pruned_half_pixel_ring_from_the_window_registers(aof, orc, synth, gpu_device):
+    """The pruned 8x8 kernel refines from its window registers where the best match is not on the window's rim and the
+    wave's refining lanes share a dy, and from memory otherwise: every shift incl. the rim (+-4: the ring leaves the
+    window), frames whose halves move differently (several dy in one wave), equalisation, a predictor, noise."""
+    W, H = 192, 160
+    shifts = [(0, 0), (4, 4), (-4, -4), (4, -3), (-3, 4), (1, -1), (3, 3), (-2, 0), (0, 4), (-4, 1)]
+    halves = [(1, 0), (0, 0), (0, 0), (0, 1), (1, 0), (-1, 1), (1, -1), (1, 1), (1, 0), (0, -1)]   # (inside the reach)
+    pairs = [synth.make_pair(W, H, 4, 900 + k, shift=sh, noise=k % 3, half=hf) for k, (sh, hf) in enumerate(zip(shifts, halves))]
+    prevs = np.stack([q[0] for q in pairs]); curs = np.stack([q[1] for q in pairs])
+    # two motions in one frame: the upper part moves like pair 1, the lower like pair 5 (waves straddle the seam)
+    a, b = synth.make_pair(W, H, 4, 950, shift=(2, -3)), synth.make_pair(W, H, 4, 950, shift=(-1, 2))
+    mixed = a[1].copy(); mixed[70:] = b[1][70:]
+    prevs = np.concatenate([prevs, a[0][None]]); curs = np.concatenate([curs, mixed[None]])
+    rng = np.random.default_rng(8)
+    curs = np.concatenate([curs, rng.integers(0, 256, (1, H, W), dtype=np.uint8)])      # unrelated: directions of junk matches
+    prevs = np.concatenate([prevs, prevs[:1]])
+    for kw in (dict(subpixel=1), dict(subpixel=1, mean_subtract=1), dict(subpixel=1, feature_threshold=0, value_threshold=70000)):
+        half_pixel_modes_match_oracle(aof, orc, aof.default_params(W, H, **kw), prevs, curs, gpu_device)
+    bright = np.clip(curs.astype(np.int16) + 23, 0, 255).astype(np.uint8)               # equalisation with clamping
+    half_pixel_modes_match_oracle(aof, orc, aof.default_params(W, H, subpixel=1, mean_subtract=1), prevs, bright, gpu_device)
+    p2 = aof.default_params(W, H, subpixel=1, pyramid_levels=2, mean_subtract=1)
+    big = [synth.make_pair(W, H, 12, 970 + k, shift=sh, noise=1, brightness=9) for k, sh in enumerate([(9, -8), (-7, 6), (5, 5), (0, -9)])]
+    half_pixel_modes_match_oracle(aof, orc, p2, np.stack([q[0] for q in big]), np.stack([q[1] for q in big]), gpu_device)
+
+
 # ---- 16x16 tiles, +-8 (configs[4] geometry): the same exactness bar for k_search_tile16<PRUNE> ----
 
 def pruned16_matches(aof, orc, p, prevs, curs, device):
@@ -303,23 +349,28 @@ def test_adaptive8_is_the_default_and_learns_from_its_own_launches(aof, orc, syn
     eng.close()
 
 
-def test_adaptive8_leaves_small_launches_and_half_pixel_contexts_to_the_exhaustive_kernel(aof, orc, synth, gpu_device):
+def test_adaptive8_leaves_small_launches_to_the_exhaustive_kernel_and_prunes_half_pixel_contexts(aof, orc, synth, gpu_device):
     import torch
     W, H = 192, 160
     prevs, curs, _ = synth.make_batch(W, H, 4, 4, 8200, noise=1)
-    for kw, reps in ((dict(), 1), (dict(subpixel=1), 720)):
+    for kw, reps, pruned in ((dict(), 1, 0), (dict(subpixel=1), 1, 0), (dict(subpixel=1), 720, 3)):
         p = aof.default_params(W, H, **kw)
         po = orc.params_from(p)
         refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(4)]
         eng = aof.FlowEngine(p, 0)
         assert eng.search_mode == aof.SEARCH_ADAPTIVE
         tp, tc = tiled(torch, prevs, reps, gpu_device), tiled(torch, curs, reps, gpu_device)
+        sub = torch.full((4 * reps, eng.nblocks(0)), 0x77, dtype=torch.uint8, device=gpu_device) if p.subpixel else None
         for _ in range(3):
-            blocks, flows, sub = eng.flow_batch(tp, tc)
+            blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
             torch.cuda.synchronize()
-        assert replicas_equal(aof, blocks, flows, refs) < 0
+            assert replicas_equal(aof, blocks, flows, refs) < 0
+            if p.subpixel:
+                got = sub.cpu().numpy()
+                for i in range(got.shape[0]):
+                    assert got[i].tobytes() == refs[i % 4]["subdirs"].tobytes(), i
         st = eng.search_stats()
-        assert st["pruned_launches"] == 0 and st["exhaustive_launches"] == 3 and st["belief"] == -1, st
+        assert st["pruned_launches"] == pruned and st["exhaustive_launches"] == 3 - pruned, st
         eng.close()
 
 
