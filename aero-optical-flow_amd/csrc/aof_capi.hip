@@ -309,12 +309,10 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
         if (a.prune) {   // (the pruned kernel has no in-launch reduction)
             PruneReport rep = {nullptr, 0, 1, 0};
             if (ctx->search_mode == AOF_SEARCH_ADAPTIVE) {
-                // (a caller who switched the in-launch reduction on gets it: that kernel does not prune)
-                SearchArgs plain = a;
-                plain.prune = 0;
-                const VoteMem vm = {ctx->d_votes, kVoteStride, ctx->h_fault, ctx->vote_deadline_ticks};
-                const bool fuses = !ctx->separate_reduce && !ctx->force_generic && lane8_votes_supported(plain, vm, ctx->votes_pairs);
-                if (fuses || !adaptive_lane8_prunes(ctx, a)) {
+                // (where the caller switched the in-launch reduction on, launches that do not prune -- too small, or
+                //  images on which it does not pay -- still get it: that kernel is the exhaustive one.  256 VGA pairs,
+                //  two batches in flight: pruned + K3 40.9 us, exhaustive with the reduction in the launch 49.9 us)
+                if (!adaptive_lane8_prunes(ctx, a)) {
                     a.prune = 0;
                     ctx->search_stats.exhaustive_launches++;
                 } else {

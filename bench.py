@@ -937,9 +937,12 @@ def main():
     traffic_step = pmc_traffic(f"{args.workload}:{n}", "step_bytes")[0]
     if args.traffic != "file" and rank == 0 and world == 1 and dist is None:
         # (behind the timed region) measure it here and now; the committed summary stays the fallback
-        flag = [] if args.search == "auto" else ["--search", args.search]
-        if args.search == "auto" and eng.variant == "tile16_lds":
-            flag = ["--search", "adaptive"]   # (the default line also times the other modes: the probe run names the headline's)
+        flag = ["--search", args.search]
+        if args.search == "auto":
+            # the default line also times the other modes behind its timed region: the probe run names the headline's --
+            # for an 8x8 context the kernel its ADAPTIVE mode settled on (a fresh context would start with the pruned one)
+            st = eng.search_stats() if eng.variant == "lane8" else None
+            flag = ["--search", "exhaustive" if st and st["exhaustive_launches"] > st["pruned_launches"] else "adaptive"]
         live = live_traffic(args, n, flag)
         if live:
             traffic, traffic_step, traffic_source = live

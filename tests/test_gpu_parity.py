@@ -596,6 +596,7 @@ def test_a_finaliser_deadline_is_an_error_not_a_valid_flow(aof, synth, gpu_devic
     idx = np.arange(n) % 8
     prev, cur = torch.from_numpy(hp[idx]).to(gpu_device), torch.from_numpy(hc[idx]).to(gpu_device)
     eng = aof.FlowEngine(p, 0)
+    eng.set_search_mode(aof.SEARCH_EXHAUSTIVE)   # (the kernel that reduces in its launch; an ADAPTIVE context may prune instead)
     _, f_ref, _ = eng.flow_batch(prev, cur)
     torch.cuda.synchronize()
     ref = aof.flows_view(f_ref)

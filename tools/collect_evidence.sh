@@ -23,9 +23,9 @@ args_of() {   # bench.py arguments and the launch size key of a workload
         *) echo "";;
     esac
 }
-# profiler runs of the 16x16 workloads name the headline mode: the default line also times the other two modes behind
-# its timed region, and k_search_tile16<true, ...> serves both the adaptive and the always-pruned mode
-mode_of() { case $1 in c5|c5h) echo "--search adaptive";; *) echo "";; esac; }
+# profiler runs name the headline's search mode: the default line also times the other two modes behind its timed region,
+# and the pruned kernels serve both the adaptive and the always-pruned mode
+mode_of() { case $1 in c2|c3|c2h|c5|c5h) echo "--search adaptive";; *) echo "";; esac; }
 key_of() { case $1 in c5|c5h) echo 256;; c1b) echo 65536;; ingest) echo 8192;; derotate) echo 1048576;; seq) echo 65536;; *) echo 1024;; esac; }
 trace() {   # tag, bench arguments...: kernel-trace summary of one bench command
     tag=$1; shift

@@ -46,21 +46,18 @@ def summarise(root, workload, pairs, out_txt=None):
     if out_txt:
         open(out_txt, "w").write("\n".join(lines) + "\n")
         print("\n".join(lines))
-    # the level-0 search is the k_search kernel that moves the most bytes
-    # (bench.py also runs the opt-in pruned search, template argument PRUNE = true: not the headline)
+    # the level-0 search is the k_search kernel that moves the most bytes (the profiled commands name their search mode,
+    # so only the headline mode's kernels run: bench.py's default line would also time the other modes)
     names = [k for k in traffic if k.startswith("k_search") or k.startswith("k_flow")]
-    def pruned(k):   # the opt-in exact-pruned 8x8 variant bench.py also runs: not part of the headline step
-        return "_pruned" in k   # (16x16 workloads are profiled with --search adaptive: only the headline mode's kernels run)
-    names = [k for k in names if not pruned(k)] or names
     if not names:   # workloads without a search kernel (ingest, derotate): the kernel that moves the most bytes
         names = list(traffic)
     search = sorted(names, key=lambda k: -sum(traffic[k]))
     if not search:
         return None
     rd, wr = traffic[search[0]]
-    # every kernel of one step (the opt-in pruned variants bench.py also runs are not part of it);
-    # a kernel name that serves two launches per step (split coarse path) counts once, at its larger launch
-    step = {k: v for k, v in traffic.items() if not pruned(k)}
+    # every kernel of one step; a kernel name that serves two launches per step (split coarse path) counts once, at its
+    # larger launch
+    step = dict(traffic)
     entry = {"kernel": search[0], "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
              "step_bytes": int(sum(a + b for a, b in step.values())), "step_kernels": sorted(step),
              "source": os.path.basename(out_txt) if out_txt else "live"}
