@@ -661,7 +661,8 @@ def main():
         batches in flight on separate HIP streams).  with_dist: the flow records of G consecutive steps
         of a lane are shipped by ONE all_gather."""
 
-        def __init__(self, prev, cur, streams, reduce_mode, use_graph, launch_bound, with_dist):
+        def __init__(self, prev, cur, streams, reduce_mode, use_graph, launch_bound, with_dist, search=None):
+            self.search = search or args.search
             self.n = n_ = prev.shape[0]
             self.dist = dist if with_dist else None
             self.reduce_mode, self.use_graph, self.launch_bound = reduce_mode, use_graph, launch_bound
@@ -715,9 +716,9 @@ def main():
                         ln.graphs.append(g)
 
         def configure(self, e):
-            if args.search != "auto":
+            if self.search != "auto":
                 e.set_search_mode({"exhaustive": aof.SEARCH_EXHAUSTIVE, "pruned": aof.SEARCH_PRUNED,
-                                   "adaptive": aof.SEARCH_ADAPTIVE}[args.search])
+                                   "adaptive": aof.SEARCH_ADAPTIVE}[self.search])
             if args.force_generic:
                 e.force_generic(True)
             e.set_reduce_fusion(self.reduce_mode == "fused")
@@ -905,7 +906,7 @@ def main():
                 r3.close()
                 del r3, prev3, cur3
             # the one-GPU reference: all total3 pairs on rank 0's GPU, the configuration the N = 1 line runs
-            ms1 = None
+            ms1 = ms1x = None
             if rank == 0:
                 if total3 <= n:
                     prev1, cur1 = prev[:total3], cur[:total3]
@@ -918,7 +919,20 @@ def main():
                     r1.step()
                 ms1 = r1.timed(steps3) / steps3 * 1e3
                 r1.close()
-                del r1, prev1, cur1
+                del r1
+                # ... and with the search the shares run: launches of 128 pairs are too small for the pruned kernel (its
+                # waves carry their hints from chunk to chunk), so the ranks search exhaustively while one GPU with all
+                # the pairs prunes -- the ratio against THIS leg is the scaling of one and the same computation
+                if args.search == "auto" and eng.variant == "lane8":
+                    r1 = Runner(prev1, cur1, c1["streams"], c1["reduce_mode"], c1["use_graph"], c1["launch_bound"], with_dist=False,
+                                search="exhaustive")
+                    r1.settle(min(args.settle_steps, 200))
+                    for _ in range(args.warmup):
+                        r1.step()
+                    ms1x = r1.timed(steps3) / steps3 * 1e3
+                    r1.close()
+                    del r1
+                del prev1, cur1
             dist.barrier()
             configs3 = {"global_pairs": total3, "pairs_per_gpu": n3, "steps": steps3, "ms_per_step": round(ms3, 5),
                         "value": round(total3 / (ms3 * 1e-3), 1), "unit": "frame-pairs/s", "scaling": "strong",
@@ -926,6 +940,8 @@ def main():
                         "one_gpu_ms_per_step": round(ms1, 5) if ms1 else None,
                         "one_gpu_value": round(total3 / (ms1 * 1e-3), 1) if ms1 else None,
                         "vs_one_gpu_1024": round(ms1 / ms3, 3) if ms1 else None,
+                        "one_gpu_exhaustive_ms_per_step": round(ms1x, 5) if ms1x else None,
+                        "vs_one_gpu_1024_exhaustive": round(ms1x / ms3, 3) if ms1x else None,
                         "note": f"{total3} pairs sharded over {world} ranks with the flow records gathered on every rank, "
                                 f"against the same {total3} pairs on rank 0's GPU alone (same job, same clock)"}
     alg_bytes = aof.algorithmic_bytes(p)

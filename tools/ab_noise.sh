@@ -1,6 +1,6 @@
 #!/bin/bash
-# Lab: builds of libaof.so (ab/*.so) against noise levels, default search mode, interleaved, one box
-#   tools/p8_ab_noise.sh <workload> <out-dir> "<noise levels>" <lib> [<lib> ...]
+# Builds of libaof.so (ab/*.so) against noise levels, default search mode, interleaved, one box
+#   tools/ab_noise.sh <workload> <out-dir> "<noise levels>" <lib> [<lib> ...]
 wl=$1; out=$2; nzs=$3; shift 3
 mkdir -p $out
 for round in 1 2; do

@@ -6,13 +6,14 @@
 # Besides the workloads of bench.py --workload, "share" collects configs[3]'s per-GPU share: the
 # 128-pair C2 step with one batch in flight / separate K3 and with two batches in flight / the
 # reduction inside the search launch, next to the 1 024-pair step of the same box; "lanes" the
-# multi-kernel workloads with two batches in flight; "latency" the per-call path.
+# multi-kernel workloads with two batches in flight; "latency" the per-call path; "noise" the search modes of the 8x8
+# workloads against noise on the newer frame.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/evidence
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-WL=${@:-c2 c3 c5 c2h c1b c5h ingest derotate seq share lanes latency}
+WL=${@:-c2 c3 c5 c2h c1b c5h ingest derotate seq share lanes latency noise}
 args_of() {   # bench.py arguments and the launch size key of a workload
     case $1 in
         c5|c5h) echo "--pairs 256";;
@@ -42,6 +43,10 @@ for wl in $WL; do
     share)
         line share_p1024 --cpu-seconds 0 --traffic file
         line share_p1024_two_batches --streams 2 --cpu-seconds 0 --traffic file
+        line share_p1024_exhaustive --search exhaustive --cpu-seconds 0 --traffic file
+        line share_p1024_exhaustive_two_batches --search exhaustive --streams 2 --cpu-seconds 0 --traffic file
+        line share_p256 --pairs 256 --steps 200 --cpu-seconds 0 --traffic file
+        line share_p512 --pairs 512 --steps 200 --cpu-seconds 0 --traffic file
         line share_p128_one_batch_separate --pairs 128 --steps 200 --streams 1 --reduce separate --cpu-seconds 0 --traffic file
         line share_p128_one_batch_fused --pairs 128 --steps 200 --streams 1 --reduce fused --cpu-seconds 0 --traffic file
         line share_p128_two_batches_separate --pairs 128 --steps 200 --streams 2 --reduce separate --cpu-seconds 0 --traffic file
@@ -56,6 +61,10 @@ for wl in $WL; do
         done
         line lanes_c3_p512 --workload c3 --pairs 512 --streams 2 --cpu-seconds 0 --traffic file
         echo "lanes done";;
+    noise)
+        cd $R && tools/search_modes_vs_noise.sh $O/noise c2 c3 c2h > $O/search_modes_vs_noise.txt 2>&1 || { echo "noise sweep failed"; tail -3 $O/search_modes_vs_noise.txt; exit 1; }
+        cd /tmp; rm -rf $O/noise
+        echo "noise done";;
     latency)
         cd $R && tools/stream_latency.sh > $O/stream_latency.txt 2> $O/stream_latency.err; cd /tmp
         timeout -k 10 200 python3 $R/bench.py --workload c1 --pairs 256 --steps 20 > $O/bench_c1.json 2> $O/bench_c1.err || { echo "bench c1 failed"; exit 1; }
@@ -68,7 +77,7 @@ for wl in $WL; do
     esac
 done
 for wl in $WL; do
-    case $wl in share|lanes|latency) continue;; esac
+    case $wl in share|lanes|latency|noise) continue;; esac
     extra="$(args_of $wl) $(mode_of $wl)"; pairs=$(key_of $wl)
     for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"; do
         tag=$(echo $set | cut -d" " -f1)

@@ -348,7 +348,7 @@ def main():
             if mode == "split" and p.pyramid_levels != 2 and not small:
                 continue   # (the separate kernels instead of k_coarse / k_flow_small)
             if mode == "default" and p.tile != 16:
-                continue   # (8x8 contexts search exhaustively by default; 16x16 contexts in the adaptive mode)
+                continue   # (a launch of two pairs: 8x8 contexts in the adaptive mode search it exhaustively; 16x16 contexts probe)
             if mode == "sequence_view":
                 # the two pairs as ONE sequence of three frames viewed twice (K1 once per frame): pair 0 = (prev0, cur0),
                 # pair 1 = (cur0, cur1)
@@ -440,6 +440,36 @@ def main():
             name = "small_lds" if small and mode in ("exhaustive", "pruned") else eng.variant
             variants[name] = variants.get(name, 0) + 1
             eng.close()
+        # 8x8 contexts on grids the flat kernel serves: the ADAPTIVE default on a launch large enough for the pruned kernel --
+        # the two pairs replicated, interleaved, to 4 096 chunks of 256 blocks and more --, three launches (nothing known yet:
+        # every wave's first chunk judges; then what the reports said), every replica against the oracle
+        nb0 = aof.grid(p, 0)[4] * aof.grid(p, 0)[5]
+        if p.tile == 8 and p.search == 4 and nb0 > 256 and rng.random() < 0.35:
+            reps = (4096 * 256 + n * nb0 - 1) // (n * nb0) + 1
+            if 2 * reps * n * p.width * p.height <= (3 << 29):
+                eng = aof.FlowEngine(p, 0)
+                rp, rc = tp.repeat(reps, 1, 1).contiguous(), tc.repeat(reps, 1, 1).contiguous()
+                subs = torch.full((reps * n, nb0), 99, dtype=torch.uint8, device=dev) if p.subpixel else None
+                for launch in range(3):
+                    blocks, flows, _ = eng.flow_batch(rp, rc, subdirs=subs)
+                    torch.cuda.synchronize()
+                    gb, gf = aof.blocks_view(blocks), aof.flows_view(flows)
+                    gs = subs.cpu().numpy() if subs is not None else None
+                    for i in range(reps * n):
+                        r = refs[i % n]
+                        ok = gb[i].tobytes() == r["blocks"].tobytes() and gf[i].tobytes() == r["flow"].tobytes()
+                        if ok and gs is not None:
+                            ok = gs[i].tobytes() == r["subdirs"].tobytes()
+                        if not ok:
+                            print(f"MISMATCH seed {s} mode adaptive_replicas launch {launch} replica {i} ({eng.search_stats()}): {kw}", flush=True)
+                            sys.exit(1)
+                st = eng.search_stats()
+                if st["pruned_launches"] < 1:
+                    print(f"seed {s}: the adaptive launch of {reps * n} pairs never ran the pruned kernel: {st}: {kw}", flush=True)
+                    sys.exit(1)
+                variants["lane8_adaptive_replicas"] = variants.get("lane8_adaptive_replicas", 0) + 1
+                eng.close()
+                del rp, rc, subs
         done += 1
         if done % 25 == 0:
             print(f"{done} cases ok ({time.time() - t0:.0f} s), skipped {skipped}, kernels {variants}", flush=True)

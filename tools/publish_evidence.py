@@ -28,6 +28,12 @@ if os.path.exists(lat):
             "# through a mailbox in pinned memory (no launch per call); launch call = duration of the hipLaunchKernelGGL that started it,\n"
             "# launch->first poll = from that call's return until the kernel's first store into the mailbox was seen (no HIP call in between).\n")
     open(os.path.join(prof, f"{prefix.split('_')[0]}_stream_latency.txt"), "w").write(head + open(lat).read()); n += 1
+nz = os.path.join(ev, "search_modes_vs_noise.txt")
+if os.path.exists(nz):
+    head = ("# tools/search_modes_vs_noise.sh: bench.py at its defaults with +-N LSB of uniform noise added to the newer frame (--noise N); per line the\n"
+            "# default (adaptive) search, and the exhaustive and the always-pruned search of the same batch timed behind it (records compared on the\n"
+            "# device: identical); `adaptive stats` = aof_search_stats of the headline's context: which kernel its launches ran.\n")
+    open(os.path.join(prof, f"{prefix}_c2_noise.txt"), "w").write(head + open(nz).read()); n += 1
 src = os.path.join(ev, "pmc_traffic.json")
 if os.path.exists(src):
     new = json.load(open(src))

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Lab: the default (adaptive) search of a workload against noise, with the other modes of the same batch from the same line
-#   tools/p8_modes.sh <out-dir> <workload> [<workload> ...]
+# The default (adaptive) search of a workload against +-N LSB of noise on the newer frame, with the other two modes of the
+# same batch from the same bench line (one box).   tools/search_modes_vs_noise.sh <out-dir> <workload> [<workload> ...]
 out=$1; shift
 mkdir -p $out
 for wl in "$@"; do
-  for nz in ${NZS:-0 4 8 16 40}; do
-    timeout -k 10 300 python bench.py --workload $wl --noise $nz --traffic file --cpu-seconds 0 > $out/${wl}_n$nz.json 2> $out/${wl}_n$nz.err || { tail -3 $out/${wl}_n$nz.err; exit 1; }
+  for nz in ${NZS:-0 2 4 8 16 40}; do
+    timeout -k 10 300 python3 ${GRAFT_REPO_ROOT:-.}/bench.py --workload $wl --noise $nz --traffic file --cpu-seconds 0 > $out/${wl}_n$nz.json 2> $out/${wl}_n$nz.err || { tail -3 $out/${wl}_n$nz.err; exit 1; }
   done
 done
 python - $out "$@" <<'PY'
@@ -13,7 +13,7 @@ import json, sys
 out, wls = sys.argv[1], sys.argv[2:]
 for wl in wls:
     print(wl, "M pairs/s: default | exhaustive | always-pruned   (K2 us default)   adaptive stats")
-    for nz in (0, 4, 8, 16, 40):
+    for nz in (0, 2, 4, 8, 12, 16, 40):
         try:
             d = json.loads(open(f"{out}/{wl}_n{nz}.json").read().strip().splitlines()[-1])
         except Exception:
