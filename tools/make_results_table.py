@@ -114,8 +114,10 @@ def share():
                     "(16 KB per rank, asynchronous, overlapped with the next step), against the ≥ 6× `north_star` asks for.  Since round 4 one GPU with all "
                     f"1 024 pairs in one launch does better than that — its adaptive search prunes: {best['ms_per_step']*1e3:.1f} µs — and the 128-pair shares cannot "
                     f"follow (a pruning hint is carried from chunk to chunk of a wave, and 2 330 chunks do not even fill the wave slots twice): against THAT step "
-                    f"eight GPUs are {best['ms_per_step']/j['ms_per_step']:.1f}× faster.  The scaling of the sharded job itself is the first figure; the second says that, at "
-                    "this problem size, half of what seven more GPUs buy can also be had from pruning on one.  With one batch in flight the 128-pair share is "
+                    f"eight GPUs are {best['ms_per_step']/j['ms_per_step']:.1f}× faster.  The first figure is the scaling of the sharded job (the same computation on both sides); "
+                    "the second compares it with a faster single-GPU algorithm that needs launches of 256 pairs and more (a 4-GPU split of the 1 024 pairs still prunes: "
+                    f"{load('share_p256')['ms_per_step']*1e3:.1f} µs per 256-pair step).  `bench.py`'s N > 1 line reports both (`configs3.vs_one_gpu_1024_exhaustive`, `.vs_one_gpu_1024`).  "
+                    "With one batch in flight the 128-pair share is "
                     "launch-bound (≈ 4.7 µs of every replayed graph are launch gaps, 5 µs the reduction): the two batches in flight are what the target needs."]
     return "\n".join(out)
 
