@@ -139,15 +139,15 @@ int aof_set_force_generic(aof_ctx *ctx, int on);
  *   16x16 tiles: a small probe kernel in front of the search computes the two-row bounds of a sample of every
  *   pair's blocks (1.6 % of them) and the search runs a pair's block rows pruned when the bounds predict that few
  *   candidates survive, exhaustively otherwise (the verdicts live in the workspace, aof_ws_layout.hints).
- *   8x8 tiles (level-0 searches of at least 4 096 x 256 blocks per launch, no half-pixel step; everything else
- *   runs EXHAUSTIVE): a probe per launch would cost more than it saves, so the CONTEXT learns from its own
- *   launches.  The pruned kernel -- whose waves run a chunk of blocks exhaustively, judge from its SADs whether
+ *   8x8 tiles (level-0 searches of at least 4 096 x 256 blocks per launch; everything else runs EXHAUSTIVE): a
+ *   probe per launch would cost more than it saves, so the CONTEXT learns from its own launches.  The pruned kernel -- whose waves run a chunk of blocks exhaustively, judge from its SADs whether
  *   rows could have been dropped, and prune the next chunks where they could -- reports the share of chunks that
  *   pruned (plain stores into pinned host memory, read at the next enqueue, never waited for).  While that share
- *   is at least 40 % the context keeps launching it (1 024 clean VGA translations: +30 % over EXHAUSTIVE);
- *   otherwise it launches the exhaustive kernel, and the pruned one once in 16 launches to look again (noise of
- *   +-16 LSB and more: -1 % against EXHAUSTIVE, where PRUNED alone loses 10 %).  A context's first launch and a
- *   graph captured from it use whatever is known at that moment.  aof_get_search_stats tells what happened. */
+ *   is at least 40 % the context keeps launching it (1 024 clean VGA translations: +40 % over EXHAUSTIVE, +20 % at
+ *   +-8 LSB of noise); otherwise it launches the exhaustive kernel, and the pruned one once in 16 launches to look
+ *   again (noise of +-16 LSB and more: within 1 % of EXHAUSTIVE, where PRUNED alone loses 12 %).  A context's first
+ *   launch and a graph captured from it use whatever is known at that moment; half-pixel configurations prune too
+ *   (+5 %).  aof_get_search_stats tells what happened. */
 #define AOF_SEARCH_EXHAUSTIVE 0
 #define AOF_SEARCH_PRUNED 1
 #define AOF_SEARCH_ADAPTIVE 2
