@@ -326,7 +326,8 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
                 }
             }
             if (a.prune) {
-                rc = launch_search_lane8(a, s, nullptr, nullptr, &rep);
+                // (dense grids: the column walk, whose lanes keep half of their window for the block below)
+                rc = lane8_cols_supported(a) ? launch_search_lane8_cols(a, s, &rep) : launch_search_lane8(a, s, nullptr, nullptr, &rep);
                 if (rep.slots) ctx->prune_expected = rep.expected;
                 break;
             }

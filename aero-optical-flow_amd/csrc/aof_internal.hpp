@@ -176,6 +176,10 @@ int launch_search_lane8(const SearchArgs &a, void *stream, const FlowTail *tail 
 // 256-block chunks of the launch: the pruned kernel carries its hints from chunk to chunk of a workgroup and
 // needs a few thousand chunks before that pays (256 VGA pairs: +9 %, 512: +20 %, 1 024: +35 % on clean translations).
 int64_t lane8_chunks(const SearchArgs &a);
+// The pruned search on dense grids as a column walk (k_search_cols8.hip): a lane keeps the lower half of its window for
+// the block below.  Same modes (a.prune 1 / 2), same report.
+bool lane8_cols_supported(const SearchArgs &a);
+int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *report = nullptr);
 constexpr int64_t kPruneMinChunks = 4096;
 // Grids of 8..256 blocks: a workgroup owns whole pairs and also writes their flow records (no K3).
 int lane8_group(const SearchArgs &a);  // pairs per workgroup, 0 = not applicable

@@ -101,6 +101,22 @@ def test_pruned_fuzz(aof, orc, synth, gpu_device, seed):
     both_modes_match_oracle(aof, orc, p, prevs, curs, gpu_device)
 
 
+def tiled(torch, arr, reps, device):
+    """`reps` copies of a small set of frames, interleaved, as one device batch."""
+    t = torch.from_numpy(arr).to(device)
+    return t.repeat((reps,) + (1,) * (t.dim() - 1)).contiguous()
+
+
+def replicas_equal(aof, blocks, flows, refs):
+    gb, gf = aof.blocks_view(blocks), aof.flows_view(flows)
+    k = len(refs)
+    for i in range(gb.shape[0]):
+        r = refs[i % k]
+        if gb[i].tobytes() != r["blocks"].tobytes() or gf[i].tobytes() != r["flow"].tobytes():
+            return i
+    return -1
+
+
 def half_pixel_modes_match_oracle(aof, orc, p, prevs, curs, device):
     """Records, directions and flow of the exhaustive and the pruned 8x8 kernel against the oracle."""
     import torch
@@ -145,6 +161,47 @@ def test_pruned_half_pixel_ring_from_the_window_registers(aof, orc, synth, gpu_d
     p2 = aof.default_params(W, H, subpixel=1, pyramid_levels=2, mean_subtract=1)
     big = [synth.make_pair(W, H, 12, 970 + k, shift=sh, noise=1, brightness=9) for k, sh in enumerate([(9, -8), (-7, 6), (5, 5), (0, -9)])]
     half_pixel_modes_match_oracle(aof, orc, p2, np.stack([q[0] for q in big]), np.stack([q[1] for q in big]), gpu_device)
+
+
+def test_pruned_walks_on_grids_that_are_not_dense(aof, orc, synth, gpu_device):
+    """The pruned 8x8 search has two walks: lanes that own a column of blocks and keep half of their window for the block
+    below (grids whose rows are one tile apart: the dense grid, and sparse grids with a row step of 8), and workgroups that
+    walk chunks of 256 blocks (every other grid of more than 256 blocks).  Sparse grids of both kinds, with and without the
+    half-pixel step, two levels and equalisation: records, directions and flows of both search modes against the oracle, and
+    the adaptive default on a launch large enough to prune."""
+    import torch
+    cases = [((320, 240), dict(grid_mode=1, num_blocks=20)),                 # 19 x 19 blocks, steps 16 / 12: chunk walk
+             ((192, 160), dict(grid_mode=1, num_blocks=20)),                 # 20 x 18, steps 9 / 8: column walk, columns 9 apart
+             ((192, 160), dict(grid_mode=1, num_blocks=24)),                 # 22 x 24, steps 8 / 6: chunk walk
+             ((192, 160), dict(grid_mode=1, num_blocks=20, subpixel=1, mean_subtract=1)),
+             ((320, 240), dict(grid_mode=1, num_blocks=20, subpixel=1)),
+             ((192, 160), dict(grid_mode=1, num_blocks=20, pyramid_levels=2, mean_subtract=1))]
+    for (W, H), kw in cases:
+        p = aof.default_params(W, H, **kw)
+        assert aof.check_params(p) == 0 and aof.grid(p, 0)[4] * aof.grid(p, 0)[5] > 256
+        reach = 9 if p.pyramid_levels == 2 else 4
+        prevs, curs, _ = synth.make_batch(W, H, 5, reach, 8600, noise=2, brightness=7 if p.mean_subtract else 0)
+        rng = np.random.default_rng(9)
+        curs[4] = rng.integers(0, 256, curs[4].shape, dtype=np.uint8)
+        po = orc.params_from(p)
+        refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(5)]
+        nb = aof.grid(p, 0)[4] * aof.grid(p, 0)[5]
+        for mode, reps in ((aof.SEARCH_EXHAUSTIVE, 1), (aof.SEARCH_PRUNED, 1), (aof.SEARCH_ADAPTIVE, (4096 * 256 // nb + 5) // 5 + 1)):
+            eng = aof.FlowEngine(p, 0)
+            eng.set_search_mode(mode)
+            tp, tc = tiled(torch, prevs, reps, gpu_device), tiled(torch, curs, reps, gpu_device)
+            sub = torch.full((5 * reps, nb), 0x77, dtype=torch.uint8, device=gpu_device) if p.subpixel else None
+            for _ in range(2):
+                blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+                torch.cuda.synchronize()
+                assert replicas_equal(aof, blocks, flows, refs) < 0, (kw, mode)
+                if sub is not None:
+                    gs = sub.cpu().numpy()
+                    for i in range(gs.shape[0]):
+                        assert gs[i].tobytes() == refs[i % 5]["subdirs"].tobytes(), (kw, mode, i)
+            if mode == aof.SEARCH_ADAPTIVE:
+                assert eng.search_stats()["pruned_launches"] >= 1
+            eng.close()
 
 
 # ---- 16x16 tiles, +-8 (configs[4] geometry): the same exactness bar for k_search_tile16<PRUNE> ----
@@ -278,22 +335,6 @@ def test_adaptive16_probe_on_narrow_tall_and_tiny_grids(aof, orc, synth, gpu_dev
 
 
 # ---- 8x8 tiles: AOF_SEARCH_ADAPTIVE, the default -- the context learns from its own launches which kernel to run ----
-
-def tiled(torch, arr, reps, device):
-    """`reps` copies of a small set of frames, interleaved, as one device batch."""
-    t = torch.from_numpy(arr).to(device)
-    return t.repeat((reps,) + (1,) * (t.dim() - 1)).contiguous()
-
-
-def replicas_equal(aof, blocks, flows, refs):
-    gb, gf = aof.blocks_view(blocks), aof.flows_view(flows)
-    k = len(refs)
-    for i in range(gb.shape[0]):
-        r = refs[i % k]
-        if gb[i].tobytes() != r["blocks"].tobytes() or gf[i].tobytes() != r["flow"].tobytes():
-            return i
-    return -1
-
 
 def test_adaptive8_is_the_default_and_learns_from_its_own_launches(aof, orc, synth, gpu_device):
     """A fresh 8x8 context searches in AOF_SEARCH_ADAPTIVE.  Launches of at least 4 096 chunks of 256 blocks go to the
