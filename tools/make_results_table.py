@@ -113,7 +113,7 @@ def share():
                     f"exhaustive search on all of them takes {same['ms_per_step']*1e3:.1f} µs at its fastest: **{same['ms_per_step']/j['ms_per_step']:.1f}×** before the gather "
                     "(16 KB per rank, asynchronous, overlapped with the next step), against the ≥ 6× `north_star` asks for.  Since round 4 one GPU with all "
                     f"1 024 pairs in one launch does better than that — its adaptive search prunes: {best['ms_per_step']*1e3:.1f} µs — and the 128-pair shares cannot "
-                    f"follow (a pruning hint is carried from chunk to chunk of a wave, and 2 330 chunks do not even fill the wave slots twice): against THAT step "
+                    f"follow (a pruning hint is carried from block to block of a wave, and 128 pairs leave the 4 096 wave slots two or three blocks each: the best pruned step measured at this size, 24.9 µs, beats the exhaustive one by 3 %): against THAT step "
                     f"eight GPUs are {best['ms_per_step']/j['ms_per_step']:.1f}× faster.  The first figure is the scaling of the sharded job (the same computation on both sides); "
                     "the second compares it with a faster single-GPU algorithm that needs launches of 256 pairs and more (a 4-GPU split of the 1 024 pairs still prunes: "
                     f"{load('share_p256')['ms_per_step']*1e3:.1f} µs per 256-pair step).  `bench.py`'s N > 1 line reports both (`configs3.vs_one_gpu_1024_exhaustive`, `.vs_one_gpu_1024`).  "
