@@ -20,6 +20,14 @@
 
 namespace aof {
 
+// (outside the anonymous namespace: profilers print kernel names with their parameter types, and the tools cut the
+//  name at the first "(anonymous namespace)::")
+struct ColsPlan {
+    int32_t segs, len;          // segments per column, block rows per segment
+    uint32_t units_per_pair;    // segs * nx padded to a multiple of 64
+    FastDiv div_units, div_nx;
+};
+
 namespace {
 
 constexpr int kColsThreads = 256;
@@ -29,12 +37,6 @@ constexpr int kColsThreads = 256;
 // 1 024 pairs: 8 rows 148 us, 3: 160; profiles/r04_p8_column_walk.txt).
 constexpr int kColsMaxRows = 8, kColsMinRows = 2;
 constexpr int64_t kColsWavesWanted = 3072;
-
-struct ColsPlan {
-    int32_t segs, len;          // segments per column, block rows per segment
-    uint32_t units_per_pair;    // segs * nx padded to a multiple of 64
-    FastDiv div_units, div_nx;
-};
 
 template <bool SUBPIXEL>
 __global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArgs a, ColsPlan plan, uint32_t total_wgs,

@@ -17,7 +17,7 @@ for mode in ("exhaustive","adaptive"):
         for r in csv.DictReader(open(f)):
             k=r["Kernel_Name"]
             if "k_search_lane8" not in k: continue
-            k=k.split("(anonymous namespace)::")[-1].split("(")[0]
+            k=k.split("(anonymous namespace)::", 1)[-1].split("(")[0]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k in acc:
         if len(next(iter(acc[k].values()))) < 20: continue
