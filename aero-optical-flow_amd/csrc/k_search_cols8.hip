@@ -22,10 +22,18 @@ namespace aof {
 
 // (outside the anonymous namespace: profilers print kernel names with their parameter types, and the tools cut the
 //  name at the first "(anonymous namespace)::")
-struct ColsPlan {
+struct ColsSegments {
     int32_t segs, len;          // segments per column, block rows per segment
     uint32_t units_per_pair;    // segs * nx padded to a multiple of 64
-    FastDiv div_units, div_nx;
+    FastDiv div_units;
+};
+// The launch's pairs [0, head_pairs) are cut into `head` segments; the pairs behind them -- the part of the launch that
+// would fill the device's wave slots only partly, at the end -- into segments half as long (`tail`), so that the last
+// waves to start are the short ones and the launch does not end on a third of the device (workgroups run in launch order).
+struct ColsPlan {
+    ColsSegments head, tail;
+    uint32_t head_pairs, head_units;   // head_units = head_pairs * head.units_per_pair
+    FastDiv div_nx;
 };
 
 namespace {
@@ -37,20 +45,26 @@ constexpr int kColsThreads = 256;
 // 1 024 pairs: 8 rows 148 us, 3: 160; profiles/r04_p8_column_walk.txt).
 constexpr int kColsMaxRows = 8, kColsMinRows = 2;
 constexpr int64_t kColsWavesWanted = 3072;
+constexpr int64_t kWaveSlots = 4096;   // 256 CUs x 4 SIMDs x 4 waves of this kernel
 
 template <bool SUBPIXEL>
-__global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArgs a, ColsPlan plan, uint32_t total_wgs,
-                                                                        PruneReport report)
+__global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArgs a, ColsPlan plan, PruneReport report)
 {
-    const uint32_t wg = xcd_remap(blockIdx.x, total_wgs);
-    const uint32_t unit = wg * kColsThreads + threadIdx.x;          // < 2^31 (launcher)
-    // (the wave's pair, in a scalar register: units_per_pair is a multiple of 64)
-    const uint32_t pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)fast_div(unit, plan.div_units));
+    // (workgroups in launch order, no XCD remap: the short segments must start last on every XCD, and the remap buys this
+    //  kernel nothing -- 133.5 against 133.5 us per 1 024 VGA pairs.  Short segments for the launch's last pairs: c3's search
+    //  kernel 180.8 -> 174.8 us, c2h's 227.7 -> 218.3, c2's 130.0 -> 128.7)
+    const uint32_t wg = blockIdx.x;
+    const uint32_t unit0 = wg * kColsThreads + threadIdx.x;          // < 2^31 (launcher)
+    // the wave's segment class and pair, in scalar registers: units per pair are multiples of 64
+    const bool in_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit0) >= plan.head_units;
+    const ColsSegments sg = in_tail ? plan.tail : plan.head;
+    const uint32_t unit = in_tail ? unit0 - plan.head_units : unit0;
+    const uint32_t pair = (in_tail ? plan.head_pairs : 0u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)fast_div(unit, sg.div_units));
     if (pair >= (uint32_t)a.n_pairs) return;                           // (whole waves)
-    const uint32_t local = unit - pair * plan.units_per_pair;
+    const uint32_t local = unit - (pair - (in_tail ? plan.head_pairs : 0u)) * sg.units_per_pair;
     const uint32_t seg = fast_div(local, plan.div_nx), bx = local - __umul24(seg, (uint32_t)a.grid.nx);
-    const bool live = local < (uint32_t)(plan.segs * a.grid.nx);
-    const int by0 = (int)seg * plan.len;
+    const bool live = local < (uint32_t)(sg.segs * a.grid.nx);
+    const int by0 = (int)seg * sg.len;
     const int W = a.w;
     constexpr int m = SUBPIXEL ? 1 : 0;
 
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArg
     // PRUNED starts optimistically in the centre row; ADAPTIVE lets the first block of every wave run exhaustively and judge
     int start_row = 4, prune_pays = a.prune == 2 ? 0 : 1;   // (wave-uniform: scalar registers)
     int seen = 0, paying = 0;
-    for (int step = 0; step < plan.len; step++) {
+    for (int step = 0; step < sg.len; step++) {
         const int by = by0 + step;
         const bool act = live && by < a.grid.ny;
         if (__ballot(act) == 0) break;                                   // (segments end together; the last one is shorter)
@@ -215,16 +229,22 @@ int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *rep
     if (report) report->expected = 0;
     if (a.n_pairs == 0) return 0;
     if (!lane8_cols_supported(a) || (a.subpixel && !a.subdirs)) return (int)hipErrorInvalidValue;
+    auto segments = [&](int len) {
+        ColsSegments g;
+        g.len = len > a.grid.ny ? a.grid.ny : len;
+        g.segs = (a.grid.ny + g.len - 1) / g.len;
+        g.units_per_pair = (uint32_t)((g.segs * a.grid.nx + 63) / 64 * 64);
+        g.div_units = fastdiv_make(g.units_per_pair);
+        return g;
+    };
+    auto waves = [&](int len) { return a.n_pairs * (int64_t)(segments(len).units_per_pair / 64); };
+    int len = kColsMaxRows;
+    while (len > kColsMinRows && waves(len) < kColsWavesWanted) len--;
     ColsPlan plan;
-    auto waves = [&](int len) { return a.n_pairs * (((int64_t)((a.grid.ny + len - 1) / len) * a.grid.nx + 63) / 64); };
-    plan.len = kColsMaxRows;
-    while (plan.len > kColsMinRows && waves(plan.len) < kColsWavesWanted) plan.len--;
-    if (plan.len > a.grid.ny) plan.len = a.grid.ny;
-    plan.segs = (a.grid.ny + plan.len - 1) / plan.len;
-    plan.units_per_pair = (uint32_t)((plan.segs * a.grid.nx + 63) / 64 * 64);
-    plan.div_units = fastdiv_make(plan.units_per_pair);
+    plan.head = segments(len);
+    plan.tail = segments(len / 2 < kColsMinRows ? kColsMinRows : len / 2);
     plan.div_nx = fastdiv_make((uint32_t)a.grid.nx);
-    const int64_t per = 0x7FFF0000ll / plan.units_per_pair;   // pairs per launch: units are indexed with 31 bits
+    const int64_t per = 0x7FFF0000ll / plan.tail.units_per_pair;   // pairs per launch: units are indexed with 31 bits
     for (int64_t done = 0; done < a.n_pairs; done += per) {
         SearchArgs s = a;
         s.n_pairs = a.n_pairs - done < per ? a.n_pairs - done : per;
@@ -234,7 +254,14 @@ int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *rep
         if (s.subdirs) s.subdirs += done * a.grid.blocks();
         if (s.pred) s.pred += done;
         if (s.sums) s.sums += done * 4;
-        const int64_t wgs = (s.n_pairs * plan.units_per_pair + kColsThreads - 1) / kColsThreads;
+        // pairs beyond the last full generation of wave slots (256 CUs x 16 waves) get the short segments
+        const int64_t wpp = plan.head.units_per_pair / 64, all = s.n_pairs * wpp, rest = all % kWaveSlots;
+        int64_t tail_pairs = 0;
+        if (rest != 0 && rest * 5 < kWaveSlots * 4 && plan.tail.len < plan.head.len && all > kWaveSlots) tail_pairs = (rest + wpp - 1) / wpp;
+        plan.head_pairs = (uint32_t)(s.n_pairs - tail_pairs);
+        plan.head_units = plan.head_pairs * plan.head.units_per_pair;
+        const int64_t units = (int64_t)plan.head_units + tail_pairs * plan.tail.units_per_pair;
+        const int64_t wgs = (units + kColsThreads - 1) / kColsThreads;
         PruneReport rep = {nullptr, 0, 1, 0};
         if (report && report->slots && done == 0) {
             rep = *report;
@@ -243,7 +270,7 @@ int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *rep
             report->expected = (uint32_t)((wgs + rep.stride - 1) / rep.stride);
         }
         hipLaunchKernelGGL(s.subpixel ? k_search_lane8_cols<true> : k_search_lane8_cols<false>, dim3((uint32_t)wgs), dim3(kColsThreads), 0,
-                           static_cast<hipStream_t>(stream), s, plan, (uint32_t)wgs, rep);
+                           static_cast<hipStream_t>(stream), s, plan, rep);
         const int rc = (int)hipGetLastError();
         if (rc) return rc;
     }
