@@ -251,8 +251,8 @@ SearchKind search_kind(const aof_ctx *ctx, const SearchArgs &a)
 }
 
 // ADAPTIVE search of the flat 8x8 kernel: does THIS launch run the pruned kernel?  The exhaustive kernel is the
-// faster one wherever nothing can be pruned (the pruned kernel's own exhaustive path costs 6-10 % more: three waves
-// per SIMD, chunks walked in sequence), and a probe in front of every launch would cost more than it saves at
+// faster one wherever nothing can be pruned (the pruned kernels' own exhaustive path costs 6-10 % more: their shape,
+// blocks walked in sequence), and a probe in front of every launch would cost more than it saves at
 // 0.2 us per pair -- so the context goes by what its PREVIOUS launches found: the pruned kernel reports how many
 // of its chunks left with "pruning pays" (PruneReport, plain stores into pinned memory that nobody waits for), the
 // context keeps using it while at least kPayingPct of them did, and otherwise runs the exhaustive kernel, with one
@@ -262,8 +262,7 @@ constexpr int kProbeEvery = 16;
 
 bool adaptive_lane8_prunes(aof_ctx *ctx, const SearchArgs &a)
 {
-    // half-pixel configurations: the pruned kernel loses even on clean translations (its refinement tail at three
-    // waves per SIMD); level-1 searches and small launches: too few chunks to carry a hint along
+    // level-1 searches and small launches: too few blocks per wave to carry a hint along
     if (a.level != 0 || !ctx->h_prune_slots || lane8_chunks(a) < kPruneMinChunks) return false;
     if (ctx->prune_expected) {
         const uint32_t tag = ctx->prune_launch_no & 0xFFFFu;
@@ -317,7 +316,7 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
                     ctx->search_stats.exhaustive_launches++;
                 } else {
                     // a context that knows pruning pays starts every wave in the pruned code (optimistic, like
-                    // PRUNED); one that does not lets the first chunk of every wave run exhaustively and judge
+                    // PRUNED); one that does not lets the first block (chunk) of every wave run exhaustively and judge
                     a.prune = ctx->prune_belief == 1 ? 1 : 2;
                     if (++ctx->prune_launch_no % 0x10000u == 0) ctx->prune_launch_no++;   // (tag 0 = never written)
                     rep.slots = ctx->h_prune_slots;
