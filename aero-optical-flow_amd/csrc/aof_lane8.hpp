@@ -267,6 +267,29 @@ __device__ __forceinline__ void refine_from_window(const uint4 (&win)[16], int u
     }
 }
 
+// The ring of a best match -- rows -1..8, bytes -1..8 -- straight from global memory (the lines were touched a moment ago):
+// ONE 16-byte load per row (ten bytes of it are used), half the load instructions of an 8-byte + a 2-byte load.  A load
+// that reaches past the end of the frame arrays does not return the bytes in front of the end either (the match in the
+// last pair's bottom-right corner: tools/fuzz_gpu.py, seed 11 517 551), so a lane whose last row would do that loads
+// byte-exactly; `records` = size of what the buffer resource covers, `ring` = offset of the ring's first byte in it.
+__device__ __forceinline__ void load_ring(__amdgpu_buffer_rsrc_t rs_cur, uint32_t ring, int W, uint32_t records, uint32_t (&rows)[10][3])
+{
+    if ((uint64_t)ring + (uint64_t)(9 * W) + 16u <= (uint64_t)records) {
+#pragma unroll
+        for (int y = 0; y < 10; y++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, ring, y * W, 0);
+            rows[y][0] = v.x; rows[y][1] = v.y; rows[y][2] = v.z & 0xFFFFu;
+        }
+    } else {
+#pragma unroll
+        for (int y = 0; y < 10; y++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_cur, ring, y * W, 0);
+            rows[y][0] = v.x; rows[y][1] = v.y;
+            rows[y][2] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_cur, ring + 8u, y * W, 0);
+        }
+    }
+}
+
 // One block: record (and direction) written to global memory and returned for the votes.
 // Returns the half-pixel direction (8 = none).  PRUNE: the wave-uniform exact pruned search;
 // start_row / prune_pays are the wave's hints carried from its previous chunk of blocks (every
@@ -467,11 +490,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
                 st.init();
                 if (have_ring) refine_from_window(win, udy, dxi - 1, ref, st);
                 if (!have_ring) {
-#pragma unroll
-                    for (int y = 0; y < 10; y++) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, ring, y * W, 0);
-                        rows[y][0] = v.x; rows[y][1] = v.y; rows[y][2] = v.z & 0xFFFFu;
-                    }
+                    load_ring(rs_cur, ring, W, records, rows);
                     for_rows<-1, 8>([&](auto yc) {
                         constexpr int Y = decltype(yc)::value;
                         uint32_t d[3] = {rows[Y + 1][0], rows[Y + 1][1], rows[Y + 1][2]};
@@ -484,13 +503,7 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
                 }
                 subdir = st.direction(rec.sad);
             } else {
-#pragma unroll
-            for (int y = 0; y < 10; y++) {
-                // ONE 16-byte load per ring row (10 bytes of it are used; the lines were touched a moment ago, and reads
-                // past the pair's frames return zero): half the load instructions of an 8-byte + a 2-byte load per row
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, ring, y * W, 0);
-                rows[y][0] = v.x; rows[y][1] = v.y; rows[y][2] = v.z & 0xFFFFu;
-            }
+            load_ring(rs_cur, ring, W, records, rows);
             RefineState<2> st;
             st.init();
             for_rows<-1, 8>([&](auto yc) {

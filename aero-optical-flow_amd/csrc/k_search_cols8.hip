@@ -182,11 +182,7 @@ __global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArg
                     if (!have_ring) {
                         const uint32_t ring = off_cur8 + (uint32_t)((dyi - 9) * W + (dxi - 1));   // (the match's row - 1: >= 0)
                         uint32_t rows[10][3];
-#pragma unroll
-                        for (int y = 0; y < 10; y++) {
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, ring, y * W, 0);
-                            rows[y][0] = v.x; rows[y][1] = v.y; rows[y][2] = v.z & 0xFFFFu;
-                        }
+                        load_ring(rs_cur, ring, W, records, rows);
                         for_rows<-1, 8>([&](auto yc) {
                             constexpr int Y = decltype(yc)::value;
                             uint32_t d[3] = {rows[Y + 1][0], rows[Y + 1][1], rows[Y + 1][2]};

@@ -163,6 +163,46 @@ def test_pruned_half_pixel_ring_from_the_window_registers(aof, orc, synth, gpu_d
     half_pixel_modes_match_oracle(aof, orc, p2, np.stack([q[0] for q in big]), np.stack([q[1] for q in big]), gpu_device)
 
 
+def test_half_pixel_ring_that_ends_on_the_last_byte_of_the_last_frame(aof, orc, synth, gpu_device):
+    """The bottom-right block of the LAST pair of a batch, matched at (+4, +4) on a frame of (8k + 18) x (8k + 18) pixels: the
+    last of the ten bytes of its ring's last row is the last byte of the frame arrays.  A 16-byte row load that reaches
+    past that byte does not return those bytes (found by tools/fuzz_gpu.py, seed 11 517 551: one direction in 150 000
+    cases): such lanes load their ring byte-exactly.  Twenty textures, each the last pair of its batch, on flat and on
+    grouped grids, every search mode and the generic kernel: directions, records and flows against the oracle."""
+    import torch
+    for (W, H), kw in (((146, 130), dict(subpixel=1)), ((226, 218), dict(subpixel=1)), ((226, 218), dict(subpixel=1, mean_subtract=1))):
+        p = aof.default_params(W, H, **kw)
+        g = aof.grid(p, 0)
+        assert g[0] + 8 * (g[4] - 1) == W - 13 and g[1] + 8 * (g[5] - 1) == H - 13
+        po = orc.params_from(p)
+        engines = {}
+        for mode in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED, "generic"):
+            eng = aof.FlowEngine(p, 0)
+            if mode == "generic":
+                eng.force_generic(True)
+            else:
+                eng.set_search_mode(mode)
+            engines[mode] = eng
+        for k in range(20):
+            n = 1 + k % 3
+            pairs = [synth.make_pair(W, H, 4, 700 + 7 * k + q, shift=(4, 4), noise=k % 4, brightness=(k % 5) * 4) for q in range(n)]
+            prevs, curs = np.stack([q[0] for q in pairs]), np.stack([q[1] for q in pairs])
+            refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
+            tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
+            for mode, eng in engines.items():
+                sub = torch.full((n, eng.nblocks(0)), 0x77, dtype=torch.uint8, device=gpu_device)
+                blocks, flows, _ = eng.flow_batch(tp, tc, subdirs=sub)
+                torch.cuda.synchronize()
+                gb, gf, gs = aof.blocks_view(blocks), aof.flows_view(flows), sub.cpu().numpy()
+                for i in range(n):
+                    assert gb[i].tobytes() == refs[i]["blocks"].tobytes(), (W, kw, mode, k, i)
+                    bad = np.flatnonzero(gs[i] != refs[i]["subdirs"])
+                    assert bad.size == 0, (W, kw, mode, k, i, bad[:8], gs[i][bad[:8]], refs[i]["subdirs"][bad[:8]])
+                    assert gf[i].tobytes() == refs[i]["flow"].tobytes(), (W, kw, mode, k, i)
+        for eng in engines.values():
+            eng.close()
+
+
 def test_pruned_walks_on_grids_that_are_not_dense(aof, orc, synth, gpu_device):
     """The pruned 8x8 search has two walks: lanes that own a column of blocks and keep half of their window for the block
     below (grids whose rows are one tile apart: the dense grid, and sparse grids with a row step of 8), and workgroups that
