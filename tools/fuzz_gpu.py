@@ -340,6 +340,12 @@ def main():
             yy, xx = np.mgrid[0:p.height, 0:p.width]
             prevs[0] = (((xx // period + yy // period) % 2) * int(rng.integers(1, 256))).astype(np.uint8)
             curs[0] = prevs[0] if rng.random() < 0.5 else 255 - prevs[0]
+        elif style == 6:
+            # the LAST pair displaced by the whole reach towards one of the four corners: blocks on the frame's rim match on
+            # the rim of their search window, and rings, windows and tiles of the last pair end where the arrays end
+            sx, sy = [(1, 1), (-1, -1), (1, -1), (-1, 1)][s % 4]
+            prevs[n - 1], curs[n - 1], _ = synth.make_pair(p.width, p.height, reach, 8000 + s, shift=(sx * reach, sy * reach),
+                                                           noise=int(rng.choice([0, 0, 2])))
         po = orc.params_from(p)
         small = small_eligible(p, aof.grid(p, 0), aof.grid(p, 1) if p.pyramid_levels == 2 else None)
         refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
