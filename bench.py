@@ -1016,6 +1016,11 @@ def main():
     mode_names = {aof.SEARCH_EXHAUSTIVE: "exhaustive", aof.SEARCH_PRUNED: "exact-pruned", aof.SEARCH_ADAPTIVE: "exact-adaptive"}
     head_mode = eng.search_mode
     out["config"]["search"] = mode_names[head_mode]
+    if head_mode != aof.SEARCH_EXHAUSTIVE:
+        out["config"]["search_note"] = ("exact partial-distortion elimination where it pays: every candidate that could win or tie is summed completely, "
+                                        "the records are the exhaustive scan's bit for bit (compared on the device behind the timed region: "
+                                        "exhaustive_search.records_identical_to_headline); exhaustive_search.per_gpu_value is the data-independent rate "
+                                        "of the same batch")
     if eng.variant == "lane8" and head_mode == aof.SEARCH_ADAPTIVE:
         # which kernel the context's launches ran (ADAPTIVE 8x8: decided per launch from the pruned kernel's own reports)
         out["config"]["adaptive_search"] = eng.search_stats()
