@@ -1,15 +1,14 @@
 // K2, pruned 8x8 search on DENSE grids, column walk (DESIGN.md "The 8x8 adaptive search").
 //
-// The chunk-walking pruned kernel (k_search_lane8.hip) is bound by memory where it prunes: a lane loads the whole
-// 16x16 window of every block (24 row loads), and the eight window rows that consecutive chunks of a workgroup share
-// are asked for one chunk-time apart -- by then an XCD's L2 has turned over, so they come from memory again (beyond-L2
-// traffic 1.15-1.2x the algorithmic bytes).  On a dense grid (block step = tile = 8 rows) the window of the block
-// BELOW a block is the same window moved down by eight rows.  So here a lane owns a COLUMN of blocks: it walks `len`
-// vertically adjacent blocks, keeps rows 8..15 of its window in registers as rows 0..7 of the next one and loads only the
-// eight new rows (16 row loads per block instead of 24, every frame byte asked for once but for the halo between
-// segments); consecutive lanes are consecutive columns, so every row load of a wave is one coalesced stretch of a
-// frame row, and the wave's blocks of one step are neighbours -- the wave-wide row dropping of pruned_row, the start
-// row and the verdict carried from block to block work as in the chunk walk (aof_lane8.hpp).
+// The chunk-walking pruned kernel (k_search_lane8.hip) loads the whole 16x16 window of every block (24 row loads per lane)
+// and, with equalisation, shifts all of it.  On a dense grid (block step = tile = 8 rows) the window of the block BELOW
+// a block is the same window moved down by eight rows.  So here a lane owns a COLUMN of blocks: it walks `len` vertically
+// adjacent blocks, keeps rows 8..15 of its window in registers as rows 0..7 of the next one and loads -- and shifts --
+// only the eight new rows (16 row loads per block instead of 24); consecutive lanes are consecutive columns, so every
+// row load of a wave is one coalesced stretch of a frame row, and the wave's blocks of one step are neighbours -- the
+// wave-wide row dropping of pruned_row, the start row and the verdict carried from block to block work as in the chunk
+// walk (aof_lane8.hpp).  What it buys is instruction count where there is most of it: the half-pixel and the equalising
+// configurations (c3's search kernel 216 -> 175 us, c2h's 267 -> 218 us per 1 024 VGA pairs; plain c2 -1..3 %).
 //
 // Units: a pair has `segs` segments of `len` block rows; unit = (pair, segment, column), `units_per_pair` of them
 // padded to a multiple of 64, so that a wave never straddles two pairs (everything that depends on the pair is scalar).
