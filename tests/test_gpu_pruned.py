@@ -503,3 +503,56 @@ def test_adaptive8_judging_kernel_is_exact_on_hard_inputs(aof, orc, synth, gpu_d
     st = eng.search_stats()
     assert st["pruned_launches"] >= 1 and st["reports_read"] >= 1, st
     eng.close()
+
+
+def test_adaptive8_launch_captured_into_a_graph(aof, orc, synth, gpu_device):
+    """A launch of the adaptive 8x8 search captured into a hipGraph holds the kernel chosen at capture time (a fresh context:
+    the pruned kernel whose first blocks judge; a context that has learnt: the one that starts pruning) and keeps writing its
+    reports into the context's pinned words on every replay.  Replays on new frames -- clean, then noisy -- return the
+    oracle's records; eager launches behind them go on learning."""
+    import torch
+    W, H, base, reps = 192, 160, 4, 720
+    p = aof.default_params(W, H)
+    po = orc.params_from(p)
+    n = base * reps
+    for learnt in (False, True):
+        eng = aof.FlowEngine(p, 0)
+        prevs, curs, _ = synth.make_batch(W, H, base, 4, 8700, noise=1)
+        prev, cur = tiled(torch, prevs, reps, gpu_device), tiled(torch, curs, reps, gpu_device)
+        blocks = torch.zeros((n, eng.nblocks(0)), dtype=torch.int32, device=gpu_device)
+        flows = torch.zeros((n, 16), dtype=torch.uint8, device=gpu_device)
+        ws = torch.zeros(aof.workspace_layout(p, n).total_bytes, dtype=torch.uint8, device=gpu_device)
+        if learnt:
+            for _ in range(2):
+                eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+                torch.cuda.synchronize()
+            assert eng.search_stats()["belief"] == 1
+        side = torch.cuda.Stream(gpu_device)
+        side.wait_stream(torch.cuda.current_stream(gpu_device))
+        with torch.cuda.stream(side):   # (warm-up on the capture stream, as torch asks for)
+            eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+        launches = eng.search_stats()["pruned_launches"]
+        rng = np.random.default_rng(3)
+        for rep in range(4):
+            hp, hc, _ = synth.make_batch(W, H, base, 4, 8710 + rep, noise=0)
+            if rep >= 2:
+                hc = np.clip(hc.astype(np.int16) + rng.integers(-40, 41, hc.shape), 0, 255).astype(np.uint8)
+            prev.copy_(tiled(torch, hp, reps, gpu_device)); cur.copy_(tiled(torch, hc, reps, gpu_device))
+            blocks.zero_(); flows.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            refs = [orc.flow_pair(po, hp[i], hc[i]) for i in range(base)]
+            assert replicas_equal(aof, blocks, flows, refs) < 0, (learnt, rep)
+        assert eng.search_stats()["pruned_launches"] == launches, "replays are not launches of the library"
+        # eager launches on the noisy frames the last replays left: the context reads the replays' reports and its own
+        for _ in range(3):
+            eng.flow_batch(prev, cur, blocks=blocks, flows=flows, workspace=ws)
+            torch.cuda.synchronize()
+            assert replicas_equal(aof, blocks, flows, refs) < 0
+        assert eng.search_stats()["belief"] == 0, eng.search_stats()
+        del g
+        eng.close()
