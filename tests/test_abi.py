@@ -29,6 +29,7 @@ def test_library_exports_every_declared_symbol(aof):
 
 def test_struct_layouts_match_header(aof, orc):
     assert ctypes.sizeof(aof.Params) == 13 * 4
+    assert ctypes.sizeof(aof.SearchStats) == 3 * 8 + 2 * 4   # aof_search_stats
     assert aof.BLOCK_DTYPE.itemsize == 4 and aof.FLOW_DTYPE.itemsize == 16
     assert aof.BLOCK_DTYPE == orc.BLOCK_DTYPE and aof.FLOW_DTYPE == orc.FLOW_DTYPE
     assert [n for n, _ in aof.Params._fields_] == list(orc.PARAM_FIELDS)
