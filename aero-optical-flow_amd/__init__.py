@@ -143,8 +143,10 @@ def _load():
         "aof_set_search_mode": (C.c_int, [VP, C.c_int]),
         "aof_get_search_mode": (C.c_int, [VP]),
         "aof_get_search_stats": (C.c_int, [VP, VP]),
+        "aof_set_search_belief": (C.c_int, [VP, C.c_int]),
         "aof_set_split_coarse": (C.c_int, [VP, C.c_int]),
         "aof_set_reduce_fusion": (C.c_int, [VP, C.c_int]),
+        "aof_set_coarse_overlap": (C.c_int, [VP, I64]),
         "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
         "aof_flow_pair_host": (C.c_int, [VP, VP, VP, VP, VP, VP]),
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
@@ -154,6 +156,7 @@ def _load():
         "aof_stream_get_stats": (C.c_int, [VP, P(StreamStats)]),
         "aof_debug_resident_fault": (C.c_int, [VP, C.c_int, C.c_uint32]),
         "aof_set_vote_deadline_us": (C.c_int, [VP, C.c_uint32]),
+        "aof_debug_vote_deadline_ticks": (C.c_int, [VP, C.c_uint32]),
         "aof_ingest_batch_device": (C.c_int, [P(IngestParams), VP, I64, I64, VP, I64, VP, VP]),
         "aof_sequence_layout": (C.c_int, [P(Params), P(SequenceParams), I64, P(SeqLayout)]),
         "aof_sequence_device": (C.c_int, [VP, P(SequenceParams), VP, I64, I64, VP, VP, VP, C.c_size_t, VP]),
@@ -334,8 +337,10 @@ class FlowEngine:
         self._check(lib.aof_set_force_generic(self._ctx, int(on)))
 
     def set_search_mode(self, mode):
-        """SEARCH_EXHAUSTIVE (default for 8x8 tiles), SEARCH_PRUNED (exact, data-dependent rate) or
-        SEARCH_ADAPTIVE (default for 16x16 tiles: pruned where a probe of the block row says it pays)."""
+        """SEARCH_ADAPTIVE (the default of every context: exact pruning where it pays -- 16x16 tiles by a probe per
+        pair, 8x8 tiles by what the context's previous launches reported), SEARCH_EXHAUSTIVE (every candidate summed
+        completely: the data-independent rate) or SEARCH_PRUNED (exact pruning always: rate depends on the images).
+        All three write the same records."""
         self._check(lib.aof_set_search_mode(self._ctx, int(mode)))
 
     @property
@@ -348,10 +353,20 @@ class FlowEngine:
         self._check(lib.aof_get_search_stats(self._ctx, C.byref(st)))
         return st.as_dict()
 
+    def set_search_belief(self, belief):
+        """Tell an ADAPTIVE 8x8 context what to assume about its images before it has launched anything:
+        1 pruning pays, 0 it does not, -1 forget (``aof_set_search_belief``)."""
+        self._check(lib.aof_set_search_belief(self._ctx, int(belief)))
+
     def set_split_coarse(self, on=True):
         """Two-level batches: run K1 / level-1 search / level-1 reduce as separate kernels (fills the
         workspace's level-1 frames) instead of the fused coarse kernel."""
         self._check(lib.aof_set_split_coarse(self._ctx, int(on)))
+
+    def set_coarse_overlap(self, pairs_per_sub_batch=-1):
+        """Two-level batches served by the fused coarse kernel: pairs per sub-batch of the overlap of the coarse
+        passes of sub-batch i + 1 with the level-0 search of sub-batch i (0 = one pass, -1 = automatic, the default)."""
+        self._check(lib.aof_set_coarse_overlap(self._ctx, int(pairs_per_sub_batch)))
 
     def set_reduce_fusion(self, on=True):
         """8x8 tiles on large grids: on=True reduces inside the search launch (opt-in); the default
@@ -537,8 +552,12 @@ class FlowEngine:
         self._check(lib.aof_debug_resident_fault(self._ctx, int(deaf), int(stop_wait_us)))
 
     def set_vote_deadline_us(self, microseconds):
-        """Test knob: deadline of the finaliser waves of the in-launch reduction."""
+        """Deadline of the finaliser waves of the in-launch reduction (at least 100 us)."""
         self._check(lib.aof_set_vote_deadline_us(self._ctx, int(microseconds)))
+
+    def debug_vote_deadline_ticks(self, ticks):
+        """Fault injection: that deadline in 10 ns ticks, unchecked (0: every finaliser gives up at once)."""
+        self._check(lib.aof_debug_vote_deadline_ticks(self._ctx, int(ticks)))
 
     def stream_graph_active(self) -> bool:
         return lib.aof_set_stream_graph(self._ctx, -1) == 1

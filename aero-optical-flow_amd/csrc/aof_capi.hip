@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -23,6 +24,8 @@
 #include "aof_internal.hpp"
 
 using namespace aof;
+
+constexpr int kOverlapMaxSubs = 16;
 
 struct aof_ctx {
     aof_params params;
@@ -95,6 +98,12 @@ struct aof_ctx {
     hipEvent_t votes_done;      // recorded behind every launch that uses d_votes
     hipStream_t votes_stream;   // stream of that launch
     bool votes_used;
+    // two-level batches in sub-batches: the coarse passes of sub-batch i + 1 on a stream of the context's own, beside
+    // the level-0 search of sub-batch i on the caller's (aof_set_coarse_overlap; enqueue_overlapped)
+    int64_t overlap_pairs;      // pairs per sub-batch; 0 = one pass over the whole batch, < 0 = automatic
+    hipStream_t coarse_stream;
+    hipEvent_t overlap_fork;    // caller's stream -> coarse stream
+    hipEvent_t overlap_done[kOverlapMaxSubs];   // coarse passes of sub-batch i -> caller's stream
 };
 
 // Vote records per context (launches of more pairs keep K3).  2 048 finaliser waves are at most 256 per XCD --
@@ -246,6 +255,11 @@ SearchKind search_kind(const aof_ctx *ctx, const SearchArgs &a)
     // 8x8 tiles run lane-per-block straight from L2 (measured faster than LDS-staged strips on every
     // dense configuration: full lane use, no staging phases, no barriers)
     if (tile16_supported(a)) return SK_TILE16;
+    if (a.prune) {   // the pruned steps' tables (68 B per block column) may not fit LDS where the exhaustive tile does: widths of ~3 000 px
+        SearchArgs x = a;
+        x.prune = 0;
+        if (tile16_supported(x)) return SK_TILE16;
+    }
     if (lane8_supported(a)) return lane8_group(a) > 0 ? SK_LANE8_GROUP : SK_LANE8;
     return SK_GENERIC;
 }
@@ -263,7 +277,8 @@ constexpr int kProbeEvery = 16;
 bool adaptive_lane8_prunes(aof_ctx *ctx, const SearchArgs &a)
 {
     // level-1 searches and small launches: too few blocks per wave to carry a hint along
-    if (a.level != 0 || !ctx->h_prune_slots || lane8_chunks(a) < kPruneMinChunks) return false;
+    static const int64_t lab_min = std::getenv("AOF_LAB_PRUNE_MIN_CHUNKS") ? std::atoll(std::getenv("AOF_LAB_PRUNE_MIN_CHUNKS")) : kPruneMinChunks;   // LAB ONLY
+    if (a.level != 0 || !ctx->h_prune_slots || lane8_chunks(a) < lab_min) return false;
     if (ctx->prune_expected) {
         const uint32_t tag = ctx->prune_launch_no & 0xFFFFu;
         uint32_t arrived = 0, paying = 0, seen = 0;
@@ -297,6 +312,7 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
     *reduced = false;
     switch (search_kind(ctx, a)) {
     case SK_TILE16:
+        if (a.prune && !tile16_supported(a)) a.prune = 0;   // (search_kind: only the exhaustive tile fits LDS at this width)
         rc = launch_search_tile16(a, s);   // (refines out of its LDS tile when directions are wanted)
         if (!rc && a.subpixel && !tile16_refines(a)) rc = launch_refine(a, s);
         break;
@@ -305,8 +321,8 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
         *reduced = true;
         break;
     case SK_LANE8: {
-        if (a.prune) {   // (the pruned kernel has no in-launch reduction)
-            PruneReport rep = {nullptr, 0, 1, 0};
+        PruneReport rep = {nullptr, 0, 1, 0};
+        if (a.prune) {
             if (ctx->search_mode == AOF_SEARCH_ADAPTIVE) {
                 // (where the caller switched the in-launch reduction on, launches that do not prune -- too small, or
                 //  images on which it does not pay -- still get it: that kernel is the exhaustive one.  256 VGA pairs,
@@ -324,41 +340,40 @@ int run_search(aof_ctx *ctx, SearchArgs a, const FlowTail &tail, bool *reduced, 
                     ctx->search_stats.pruned_launches++;
                 }
             }
-            if (a.prune) {
-                // (dense grids: the column walk, whose lanes keep half of their window for the block below)
-                rc = lane8_cols_supported(a) ? launch_search_lane8_cols(a, s, &rep) : launch_search_lane8(a, s, nullptr, nullptr, &rep);
-                if (rep.slots) ctx->prune_expected = rep.expected;
-                break;
-            }
         }
-        // search + reduction in one launch when the context's vote memory can serve it; launches on
-        // another stream than the last one wait for that one first (the records are shared)
+        // (dense grids prune as a column walk, whose lanes keep half of their window for the block below)
+        const bool cols = a.prune && lane8_cols_supported(a);
+        auto plain = [&]() -> int {   // K3 follows
+            if (cols) return launch_search_lane8_cols(a, s, &rep);
+            return a.prune ? launch_search_lane8(a, s, nullptr, nullptr, &rep) : launch_search_lane8(a, s);
+        };
+        // search + reduction in one launch when the context's vote memory can serve it (the exhaustive flat kernel and
+        // the column walk have that form; the chunk-walking pruned kernel has not); launches on another stream than the
+        // last one wait for that one first (the records are shared)
         const VoteMem vm = {ctx->d_votes, kVoteStride, ctx->h_fault, ctx->vote_deadline_ticks};
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (ctx->separate_reduce || ctx->force_generic || !lane8_votes_supported(a, vm, ctx->votes_pairs) ||
-            hipStreamIsCapturing(s, &cap) != hipSuccess) {
-            rc = launch_search_lane8(a, s);
-            break;
-        }
-        const bool eager = cap == hipStreamCaptureStatusNone;
+        const bool votes_fit = cols ? lane8_cols_votes_supported(a, vm, ctx->votes_pairs)
+                                    : (!a.prune && lane8_votes_supported(a, vm, ctx->votes_pairs));
+        const bool eager = hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
         // A captured graph that holds an in-launch reduction is replayed whenever its owner likes and records
         // no votes_done event: eager launches on this context keep to the separate K3 from then on, so that
         // the library never puts a second user on the vote records behind the graph's back.
-        if (eager && ctx->votes_captured) {
-            rc = launch_search_lane8(a, s);
-            break;
+        if (ctx->separate_reduce || ctx->force_generic || !votes_fit || (eager && ctx->votes_captured)) {
+            rc = plain();
+        } else {
+            if (eager && ctx->votes_used && ctx->votes_stream != s &&
+                hipStreamWaitEvent(s, ctx->votes_done, 0) != hipSuccess)
+                return fail(ctx, -EIO, "cannot order the launch behind the context's previous one");
+            rc = cols ? launch_search_lane8_cols(a, s, &rep, &tail, &vm) : launch_search_lane8(a, s, &tail, &vm);
+            if (!rc && eager) {
+                rc = (int)hipEventRecord(ctx->votes_done, s);
+                ctx->votes_stream = s;
+                ctx->votes_used = true;
+            }
+            if (!rc && !eager) ctx->votes_captured = true;   // (replays are the owner's to order: include/aof.h)
+            *reduced = true;
         }
-        if (eager && ctx->votes_used && ctx->votes_stream != s &&
-            hipStreamWaitEvent(s, ctx->votes_done, 0) != hipSuccess)
-            return fail(ctx, -EIO, "cannot order the launch behind the context's previous one");
-        rc = launch_search_lane8(a, s, &tail, &vm);
-        if (!rc && eager) {
-            rc = (int)hipEventRecord(ctx->votes_done, s);
-            ctx->votes_stream = s;
-            ctx->votes_used = true;
-        }
-        if (!rc && !eager) ctx->votes_captured = true;   // (replays are the owner's to order: include/aof.h)
-        *reduced = true;
+        if (a.prune && rep.slots) ctx->prune_expected = rep.expected;
         break;
     }
     default:
@@ -503,6 +518,66 @@ int enqueue_fine(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, hip
                          v.hist0 + (size_t)first * hist_bytes_per_pair(p, 0), AOF_K_SEARCH, AOF_K_REDUCE, s);
 }
 
+// Two-level batches whose coarse passes run as the fused kernel (C3): k_coarse keeps one 512-lane workgroup per CU --
+// two wave slots per SIMD stay free -- and spends a third of its time streaming frames with its VALU idle, while the
+// level-0 search is four waves per SIMD of SAD issue and row-load latency.  One after the other they add up; side by
+// side they share the CUs.  So the batch is cut into sub-batches and the coarse passes of sub-batch i + 1 run on the
+// context's own stream beside the level-0 search of sub-batch i on the caller's:
+//     caller's stream:  fork ............ wait(0) fine(0) wait(1) fine(1) ... wait(k) fine(k)
+//     coarse stream:    wait(fork) coarse(0) done(0) coarse(1) done(1) ... coarse(k) done(k)
+// The last wait joins the coarse stream back into the caller's (so the sequence can be captured into a hipGraph from
+// the caller's stream), the coarse stream runs ahead without ever waiting for the searches, and every region of the
+// workspace is written by exactly one sub-batch.  Pairs per sub-batch: 0 = one pass (no overlap).
+int64_t overlap_sub_batch(const aof_ctx *ctx, const BatchView &v, int64_t n_pairs)
+{
+    const aof_params &p = ctx->params;
+    if (!ctx->coarse_stream || ctx->overlap_pairs == 0 || p.pyramid_levels != 2 || ctx->force_generic || ctx->split_coarse ||
+        ctx->k1_ready)
+        return 0;
+    if (!coarse_fused_supported(coarse_args(ctx, v, 0, n_pairs, v.sums))) return 0;
+    // automatic: sub-batches of at least one workgroup of k_coarse per CU and enough 256-block chunks for the level-0
+    // search to prune (kPruneMinChunks), at most kOverlapMaxSubs of them, and nothing to overlap below two
+    int64_t sub = ctx->overlap_pairs;
+    if (sub < 0) {
+        sub = ctx->cus;
+        const int64_t prunes = (kPruneMinChunks * 256 + ctx->g0.blocks() - 1) / ctx->g0.blocks();
+        if (sub < prunes) sub = (prunes + ctx->cus - 1) / ctx->cus * ctx->cus;
+    }
+    if (sub * kOverlapMaxSubs < n_pairs) sub = (n_pairs + kOverlapMaxSubs - 1) / kOverlapMaxSubs;
+    return n_pairs >= 2 * sub ? sub : 0;
+}
+
+int enqueue_overlapped(aof_ctx *ctx, const BatchView &v, int64_t n_pairs, int64_t sub, hipStream_t s)
+{
+    hipStream_t cs = ctx->coarse_stream;
+    if (std::getenv("AOF_LAB_OVERLAP_SAME_STREAM")) {   // LAB ONLY: sub-batches one after the other on the caller's stream
+        int rc = 0;
+        for (int64_t first = 0; first < n_pairs && !rc; first += sub) {
+            const int64_t m = n_pairs - first < sub ? n_pairs - first : sub;
+            rc = enqueue_coarse(ctx, v, first, m, s);
+            if (!rc) rc = enqueue_fine(ctx, v, first, m, s);
+        }
+        return rc;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->overlap_fork, s));
+    HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->overlap_fork, 0));
+    int rc = 0;
+    // (all coarse launches first: the host never stands between the coarse stream and its next kernel)
+    int k = 0;
+    for (int64_t first = 0; first < n_pairs && !rc; first += sub, k++) {
+        rc = enqueue_coarse(ctx, v, first, n_pairs - first < sub ? n_pairs - first : sub, cs);
+        if (!rc && hipEventRecord(ctx->overlap_done[k], cs) != hipSuccess) rc = fail(ctx, -EIO, "event record on the coarse stream");
+    }
+    // Whatever happened, the coarse stream joins the caller's again (a capture must not end with a stream left forked)
+    const int subs = k;
+    k = 0;
+    for (int64_t first = 0; first < n_pairs && k < subs; first += sub, k++) {
+        if (hipStreamWaitEvent(s, ctx->overlap_done[k], 0) != hipSuccess && !rc) rc = fail(ctx, -EIO, "event wait on the caller's stream");
+        if (!rc) rc = enqueue_fine(ctx, v, first, n_pairs - first < sub ? n_pairs - first : sub, s);
+    }
+    return rc;
+}
+
 // Views of one batch inside the caller's buffers and workspace.
 BatchView batch_view(const aof_ctx *ctx, const aof_ws_layout &L, const uint8_t *d_prev, const uint8_t *d_cur,
                      int64_t pair_stride, aof_block *d_blocks, uint8_t *d_subdirs, aof_flow *d_flows, void *d_workspace)
@@ -639,6 +714,19 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
         ctx->h_prune_slots = ctx->h_fault + 16;
         ctx->votes_pairs = kVotePairs;
     }
+    if (p->pyramid_levels == 2 && p->tile == 8 && p->search == 4) {
+        // the second stream and the events of the sub-batch overlap (made here: a call only enqueues, so that it can be captured)
+        DeviceGuard guard(device);
+        bool ok = hipStreamCreateWithFlags(&ctx->coarse_stream, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&ctx->overlap_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < kOverlapMaxSubs; i++)
+            ok = hipEventCreateWithFlags(&ctx->overlap_done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            aof_destroy(ctx);
+            return -EIO;
+        }
+        ctx->overlap_pairs = 0;
+    }
     ctx->vote_deadline_ticks = kVoteDeadlineTicks;
     ctx->rstop_wait_s = 1.0;
     ctx->separate_reduce = true;   // the in-launch reduction is opt-in (aof_set_reduce_fusion)
@@ -667,6 +755,7 @@ void aof_destroy(aof_ctx *ctx)
     if (!leak && ctx->stream && (e = drain_bounded(ctx->stream, kDrainS)) != hipSuccess) leak = true;
     if (!leak && ctx->votes_done && ctx->votes_used && (e = event_wait_bounded(ctx->votes_done, kDrainS)) != hipSuccess)
         leak = true;
+    if (!leak && ctx->coarse_stream && (e = drain_bounded(ctx->coarse_stream, kDrainS)) != hipSuccess) leak = true;
     if (ctx->ev) {
         for (int k = 0; k < AOF_K_COUNT; k++)
             for (int r = 0; r < AOF_PROFILE_RING; r++)
@@ -695,6 +784,9 @@ void aof_destroy(aof_ctx *ctx)
     if (ctx->d_flow) (void)hipFree(ctx->d_flow);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->votes_done) (void)hipEventDestroy(ctx->votes_done);
+    if (ctx->coarse_stream) (void)hipStreamDestroy(ctx->coarse_stream);
+    if (ctx->overlap_fork) (void)hipEventDestroy(ctx->overlap_fork);
+    for (int i = 0; i < kOverlapMaxSubs; i++) if (ctx->overlap_done[i]) (void)hipEventDestroy(ctx->overlap_done[i]);
     if (ctx->d_votes) (void)hipFree(ctx->d_votes);
     if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     delete ctx;
@@ -708,6 +800,16 @@ int aof_get_search_stats(const aof_ctx *ctx, aof_search_stats *out)
 {
     if (!ctx || !out) return -EINVAL;
     *out = ctx->search_stats;
+    return 0;
+}
+
+int aof_set_search_belief(aof_ctx *ctx, int belief)
+{
+    if (!ctx || belief < -1 || belief > 1) return -EINVAL;
+    ctx->prune_belief = belief;
+    ctx->search_stats.belief = belief;
+    ctx->prune_since_probe = 0;
+    ctx->prune_expected = 0;   // (reports of earlier launches no longer overrule the caller)
     return 0;
 }
 
@@ -860,6 +962,7 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         }
     }
 
+    if (const int64_t sub = overlap_sub_batch(ctx, v, n_pairs)) return enqueue_overlapped(ctx, v, n_pairs, sub, s);
     rc = enqueue_coarse(ctx, v, 0, n_pairs, s);
     if (!rc) rc = enqueue_fine(ctx, v, 0, n_pairs, s);
     return rc;
@@ -868,6 +971,20 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
 }  // extern "C"
 
 namespace aof {
+
+// What every entry point that enqueues work on a context checks before its first launch: the sticky device-side
+// condition, and that the calling thread's current device is the context's.  Sets aof_last_error.
+int precheck(aof_ctx *ctx)
+{
+    if (int sticky = sticky_error(ctx)) return sticky;
+    int cur_dev = -1;
+    if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev != ctx->device)
+        return fail(ctx, -EINVAL, "context was created for device %d but the calling thread's current "
+                                  "device is %d", ctx->device, cur_dev);
+    return 0;
+}
+
+int ctx_fail(aof_ctx *ctx, int code, const char *what) { return fail(ctx, code, "%s", what); }
 
 // Would a sequence-view call (frames viewed twice, n_pairs = frames - 1) run K1 as a pass of its own?  Mirrors the
 // choices of aof_flow_batch_device / enqueue_coarse.  The sequence pipeline asks, because its ingest kernel can
@@ -911,6 +1028,14 @@ int aof_set_split_coarse(aof_ctx *ctx, int on)
     { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }   // it runs the kernels chosen so far
     if ((on != 0) != ctx->split_coarse) drop_push_graphs(ctx);
     ctx->split_coarse = on != 0;
+    return 0;
+}
+
+int aof_set_coarse_overlap(aof_ctx *ctx, int64_t pairs_per_sub_batch)
+{
+    if (!ctx) return -EINVAL;
+    if (!ctx->coarse_stream) return pairs_per_sub_batch == 0 ? 0 : fail(ctx, -EINVAL, "the context has no coarse passes to overlap (one level, or not 8x8 tiles over +-4)");
+    ctx->overlap_pairs = pairs_per_sub_batch;
     return 0;
 }
 
@@ -1100,7 +1225,7 @@ static int run_one(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_cur, ao
         else
             std::memset(subdirs, 8, nb);
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (const hipError_t e = drain_bounded(ctx->stream, kDrainS)) return wedge(ctx, "waiting for the pair's kernels and copies", e);
     return 0;
 }
 
@@ -1156,7 +1281,8 @@ int aof_stream_push_host(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow)
     if (ctx->zero_copy) std::memcpy(ctx->h_frames[slot], frame, bytes);
     else HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames[slot], frame, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->have_prev) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may free `frame` on return
+        // caller may free `frame` on return
+        if (const hipError_t e = drain_bounded(ctx->stream, kDrainS)) return wedge(ctx, "waiting for the first frame's copy", e);
         ctx->cur_slot = slot;
         ctx->have_prev = true;
         std::memset(flow, 0, sizeof(*flow));
@@ -1226,8 +1352,8 @@ static int stream_push_graph(aof_ctx *ctx, const uint8_t *frame, aof_flow *flow,
             }
         }
     } else if (e == hipSuccess) {
-        e = hipStreamSynchronize(ctx->stream);
-        *flow = *ctx->h_flow;
+        e = drain_bounded(ctx->stream, kDrainS);
+        if (e == hipSuccess) *flow = *ctx->h_flow;
     }
     if (e != hipSuccess) {
         ctx->have_prev = false;
@@ -1375,7 +1501,17 @@ int aof_stream_get_stats(const aof_ctx *ctx, aof_stream_stats *out)
 int aof_set_vote_deadline_us(aof_ctx *ctx, uint32_t microseconds)
 {
     if (!ctx) return -EINVAL;
+    // below 100 us every finaliser wave would give up on its first polls, write a zero record and raise the sticky fault
+    // word: one call would disable the context for good
+    if (microseconds < 100u) return fail(ctx, -EINVAL, "vote deadline of %u us: at least 100 us", microseconds);
     ctx->vote_deadline_ticks = microseconds > 10000000u ? 1000000000u : microseconds * 100u;   // 100 MHz counter
+    return 0;
+}
+
+int aof_debug_vote_deadline_ticks(aof_ctx *ctx, uint32_t ticks)
+{
+    if (!ctx) return -EINVAL;
+    ctx->vote_deadline_ticks = ticks;   // (fault injection: 0 makes every finaliser wave give up at once)
     return 0;
 }
 

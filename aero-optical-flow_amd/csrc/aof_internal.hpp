@@ -179,7 +179,10 @@ int64_t lane8_chunks(const SearchArgs &a);
 // The pruned search on dense grids as a column walk (k_search_cols8.hip): a lane keeps the lower half of its window for
 // the block below.  Same modes (a.prune 1 / 2), same report.
 bool lane8_cols_supported(const SearchArgs &a);
-int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *report = nullptr);
+// tail + votes: the reduction in the same launch (k_flow_lane8_cols), as launch_search_lane8 does for the exhaustive scan
+bool lane8_cols_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t capacity_pairs);
+int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *report = nullptr, const FlowTail *tail = nullptr,
+                             const VoteMem *votes = nullptr);
 constexpr int64_t kPruneMinChunks = 4096;
 // Grids of 8..256 blocks: a workgroup owns whole pairs and also writes their flow records (no K3).
 int lane8_group(const SearchArgs &a);  // pairs per workgroup, 0 = not applicable
@@ -249,6 +252,10 @@ inline int sequence_rounds(int64_t n_frames)   // smallest R with 4^R > n_frames
     return r;
 }
 int launch_sequence_output(const SequenceArgs &a, void *stream);
+// (aof_capi.hip) sticky fault / wedged state and current-device check of a context, before anything is enqueued; and
+// aof_last_error's text for the callers outside aof_capi.hip
+int precheck(aof_ctx *ctx);
+int ctx_fail(aof_ctx *ctx, int code, const char *what);
 // (aof_capi.hip) the flow of a frame sequence for the pipeline: does the call run K1 as a pass of its own, and the
 // call itself with K1's outputs already in the workspace
 bool sequence_runs_k1(aof_ctx *ctx, const uint8_t *d_frames, int64_t n_pairs, void *d_workspace);

@@ -237,6 +237,51 @@ __device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint3
     }
 }
 
+// Where a wave that knows nothing yet starts its pruned search (round 5).  A pruned block that starts in the wrong dy row
+// costs 1.4x an exhaustive one (its first row sets no useful bound, and neither do the rows between it and the right
+// one), and on a walk of two or three blocks -- a launch of 128 VGA pairs -- the first block is a third to a half of
+// the work.  So the first block VOTES: of every dy row it sums what pruned_row's first test sees (tile rows 0 and 4:
+// 16 of 64 pixels per candidate, 12 SAD instructions), every lane names the row with its smallest partial SAD, and the
+// wave starts in the row most needing lanes name -- 108 SAD instructions against the 432 of a block, in front of a
+// pruned search that then drops eight of nine rows under a global motion.  A guess about speed only.
+template <int D>
+__device__ __forceinline__ uint32_t partial_row_key(const uint4 (&win)[16], const uint32_t (&ref)[8][2])
+{
+    u64 alo = 0, ahi = 0;
+    uint32_t a8 = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r += 4) {
+        const uint4 w = win[D + r];
+        const u64 p01 = pack64(w.x, w.y), p23 = pack64(w.z, w.w), p12 = middle64(p01, p23);
+        alo = qsad(p01, ref[r][0], alo);
+        ahi = qsad(p12, ref[r][0], ahi);
+        alo = qsad(p12, ref[r][1], alo);
+        ahi = qsad(p23, ref[r][1], ahi);
+        a8 = __builtin_amdgcn_sad_hi_u8(w.z, ref[r][0], a8);
+        a8 = __builtin_amdgcn_sad_hi_u8(w.w, ref[r][1], a8);
+    }
+    const uint32_t m = pk_min_u16(pk_min_u16((uint32_t)alo, (uint32_t)(alo >> 32)), pk_min_u16((uint32_t)ahi, (uint32_t)(ahi >> 32)));
+    const uint32_t m9 = pk_min_u16(m, a8 | 0xFFFFu);
+    return (min(m9 & 0xFFFFu, m9 >> 16) << 4) | (uint32_t)D;
+}
+
+__device__ __forceinline__ int vote_start_row(const uint4 (&win)[16], const uint32_t (&ref)[8][2], unsigned long long needing)
+{
+    uint32_t key = 0xFFFFFFFFu;
+    for_rows<0, 8>([&](auto dc) {
+        constexpr int D = decltype(dc)::value;
+        key = min(key, partial_row_key<D>(win, ref));
+    });
+    const int mine = (int)(key & 15u);
+    int row = 4, most = 0;   // (scalar: nine ballots and population counts)
+#pragma unroll
+    for (int d = 0; d < 9; d++) {
+        const int n = __popcll(__ballot(mine == d) & needing);
+        if (n > most) { most = n; row = d; }
+    }
+    return row;
+}
+
 // Half-pixel refinement with the ring taken out of the 16x16 window in registers: rows udy-1 .. udy+8 (udy wave-uniform,
 // 1..7: compile-time inside the switch), bytes o .. o+9 (o per lane, 0..6: a v_alignbyte per dword).  Row by row, so
 // that nothing but the window and the refinement's own state is live (the kernel stays at four waves per SIMD).
@@ -438,7 +483,8 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
                 start_row = (int)((uint32_t)__shfl((int)best, src, 64) & 0xFFFFu) / 9;
                 prune_pays = droppable >= kJudgedRowsToPrune;
             } else {
-                const int start = __builtin_amdgcn_readfirstlane(start_row);
+                int start = __builtin_amdgcn_readfirstlane(start_row);
+                if (start < 0) start = __builtin_amdgcn_readfirstlane(vote_start_row(win, ref, needing));   // (nothing known yet)
                 const int dropped = pruned_search(win, ref, needing, start, best);
                 // the wave's next chunk starts where its first live block matched
                 const int src = __ffsll((long long)needing) - 1;

@@ -90,12 +90,16 @@ int aof_sequence_device(aof_ctx *ctx, const aof_sequence_params *sp, const uint8
     if (rc) return rc;
     aof_seq_layout L;
     rc = aof_sequence_layout(&p, sp, n_frames, &L);
+    if (rc) return ctx_fail(ctx, rc, "sequence parameters do not match the context (crop size, frame count)");
+    // before the first launch (the ingest kernel below): a faulted or wedged context, or a thread on another
+    // device, must not put work into the caller's workspace
+    rc = precheck(ctx);
     if (rc) return rc;
     if (n_frames == 0) return 0;
-    if (!d_camera || !d_time_us || !d_workspace) return -EINVAL;
-    if (workspace_bytes < L.total_bytes) return -ENOSPC;
-    if (reinterpret_cast<uintptr_t>(d_workspace) % 256) return -EINVAL;
-    if (sp->derotate && !d_gyro) return -EINVAL;
+    if (!d_camera || !d_time_us || !d_workspace) return ctx_fail(ctx, -EINVAL, "null camera, time stamp or workspace pointer");
+    if (workspace_bytes < L.total_bytes) return ctx_fail(ctx, -ENOSPC, "sequence workspace smaller than aof_sequence_layout().total_bytes");
+    if (reinterpret_cast<uintptr_t>(d_workspace) % 256) return ctx_fail(ctx, -EINVAL, "workspace must be 256-byte aligned");
+    if (sp->derotate && !d_gyro) return ctx_fail(ctx, -EINVAL, "de-rotation needs the gyro samples");
     Scratch s;
     scratch_layout(&p, n_frames, &s);
     uint8_t *ws = static_cast<uint8_t *>(d_workspace);

@@ -15,6 +15,7 @@
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
 #include "aof_lane8.hpp"
+#include "aof_reduce.hpp"
 #include "aof_refine.hpp"
 
 namespace aof {
@@ -34,6 +35,13 @@ struct ColsPlan {
     uint32_t head_pairs, head_units;   // head_units = head_pairs * head.units_per_pair
     FastDiv div_nx;
 };
+// VOTE: the reduction in the same launch (aof_reduce.hpp: vote_and_arrive / await_votes_and_finalise, as in
+// k_flow_lane8_flat).  Workgroups [0, search_wgs) search and vote, the ones behind them are finalisers, one wave per pair.
+struct ColsVotes {
+    uint32_t search_wgs;
+    FlowTail tail;
+    VoteMem votes;
+};
 
 namespace {
 
@@ -46,8 +54,8 @@ constexpr int kColsMaxRows = 8, kColsMinRows = 2;
 constexpr int64_t kColsWavesWanted = 3072;
 constexpr int64_t kWaveSlots = 4096;   // 256 CUs x 4 SIMDs x 4 waves of this kernel
 
-template <bool SUBPIXEL>
-__global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArgs a, ColsPlan plan, PruneReport report)
+template <bool SUBPIXEL, bool VOTE>
+__device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &plan, const PruneReport &report, const VoteMem *votes)
 {
     // (workgroups in launch order, no XCD remap: the short segments must start last on every XCD, and the remap buys this
     //  kernel nothing -- 133.5 against 133.5 us per 1 024 VGA pairs.  Short segments for the launch's last pairs: c3's search
@@ -110,8 +118,10 @@ __global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArg
             for (int s = 0; s < 8; s++) win[s] = sat_add_u8x16(win[s], delta);
         }
     }
-    // PRUNED starts optimistically in the centre row; ADAPTIVE lets the first block of every wave run exhaustively and judge
-    int start_row = 4, prune_pays = a.prune == 2 ? 0 : 1;   // (wave-uniform: scalar registers)
+    // ADAPTIVE lets the first block of every wave run exhaustively and judge; PRUNED (a caller, or a context whose launches
+    // have reported that pruning pays) prunes from the first block on -- under a predictor it starts in the centre row,
+    // without one the first block votes for the row (vote_start_row, aof_lane8.hpp)
+    int start_row = a.pred ? 4 : -1, prune_pays = a.prune == 2 ? 0 : 1;   // (wave-uniform: scalar registers)
     int seen = 0, paying = 0;
     for (int step = 0; step < sg.len; step++) {
         const int by = by0 + step;
@@ -155,6 +165,7 @@ __global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArg
                 best = exhaustive_search_judged(win, ref, needing, droppable);
                 prune_pays = __builtin_amdgcn_readfirstlane(droppable >= kJudgedRowsToPrune ? 1 : 0);
             } else {
+                if (start_row < 0) start_row = __builtin_amdgcn_readfirstlane(vote_start_row(win, ref, needing));
                 const int dropped = pruned_search(win, ref, needing, start_row, best);
                 prune_pays = __builtin_amdgcn_readfirstlane(dropped >= 2 ? 1 : 0);
             }
@@ -201,6 +212,17 @@ __global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArg
             slots[slot] = __builtin_bit_cast(uint32_t, rec);
             if constexpr (SUBPIXEL) dirs[slot] = (uint8_t)subdir;
         }
+        if constexpr (VOTE) {
+            // a wave lies inside one pair: its blocks of this step vote and arrive with two or three atomics (one motion)
+            const bool ok = act && (uint32_t)rec.sad < (uint32_t)a.value_threshold;   // skipped = 0xFFFF
+            int hx = 0, hy = 0;
+            if constexpr (SUBPIXEL) {
+                hx = (subdir == 0 || subdir == 1 || subdir == 7) ? 1 : ((subdir == 3 || subdir == 4 || subdir == 5) ? -1 : 0);
+                hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
+            }
+            const int centre = 2 * a.hist_range + 1;
+            vote_and_arrive(*votes, a.hist_range, pair, act, ok, 2 * rec.dx + hx + centre, 2 * rec.dy + hy + centre);
+        }
         // the lower half of this window is the upper half of the next block's
 #pragma unroll
         for (int s = 0; s < 8; s++) win[s] = win[s + 8];
@@ -211,6 +233,24 @@ __global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArg
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+template <bool SUBPIXEL>
+__global__ __launch_bounds__(kColsThreads, 4) void k_search_lane8_cols(SearchArgs a, ColsPlan plan, PruneReport report)
+{
+    cols_walk<SUBPIXEL, false>(a, plan, report, nullptr);
+}
+
+// The same walk with the reduction in the launch: no K3 behind it (launches of up to the context's vote records).
+template <bool SUBPIXEL>
+__global__ __launch_bounds__(kColsThreads, 4) void k_flow_lane8_cols(SearchArgs a, ColsPlan plan, PruneReport report, ColsVotes cv)
+{
+    if (blockIdx.x >= cv.search_wgs) {   // (uniform in the workgroup)
+        const uint32_t pair = (blockIdx.x - cv.search_wgs) * (kColsThreads >> 6) + (threadIdx.x >> 6);
+        if (pair < (uint32_t)a.n_pairs) await_votes_and_finalise(cv.votes, cv.tail, pair);
+        return;
+    }
+    cols_walk<SUBPIXEL, true>(a, plan, report, &cv.votes);
+}
+
 }  // namespace
 
 bool lane8_cols_supported(const SearchArgs &a)
@@ -219,7 +259,14 @@ bool lane8_cols_supported(const SearchArgs &a)
     return lane8_supported(a) && a.grid.step_y == 8 && a.grid.nx >= 16 && a.grid.ny >= 2 && a.grid.blocks() > 256;
 }
 
-int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *report)
+bool lane8_cols_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t capacity_pairs)
+{
+    const int n = 2 * (2 * a.hist_range + 1) + 1;
+    if (!lane8_cols_supported(a) || !votes.base || !votes.fault || n > 62 || votes.stride < (uint32_t)(2 + 2 * n)) return false;
+    return a.n_pairs <= capacity_pairs;   // (one launch: capacity is far below the 31-bit unit index)
+}
+
+int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *report, const FlowTail *tail, const VoteMem *votes)
 {
     if (report) report->expected = 0;
     if (a.n_pairs == 0) return 0;
@@ -264,8 +311,19 @@ int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *rep
             report->stride = rep.stride;
             report->expected = (uint32_t)((wgs + rep.stride - 1) / rep.stride);
         }
-        hipLaunchKernelGGL(s.subpixel ? k_search_lane8_cols<true> : k_search_lane8_cols<false>, dim3((uint32_t)wgs), dim3(kColsThreads), 0,
-                           static_cast<hipStream_t>(stream), s, plan, rep);
+        if (tail && votes) {
+            if (done != 0 || s.n_pairs != a.n_pairs) return (int)hipErrorInvalidValue;   // (lane8_cols_votes_supported)
+            ColsVotes cv;
+            cv.search_wgs = (uint32_t)wgs;
+            cv.tail = *tail;
+            cv.votes = *votes;
+            const int64_t finalisers = (s.n_pairs + (kColsThreads >> 6) - 1) / (kColsThreads >> 6);   // one wave per pair
+            hipLaunchKernelGGL(s.subpixel ? k_flow_lane8_cols<true> : k_flow_lane8_cols<false>, dim3((uint32_t)(wgs + finalisers)),
+                               dim3(kColsThreads), 0, static_cast<hipStream_t>(stream), s, plan, rep, cv);
+        } else {
+            hipLaunchKernelGGL(s.subpixel ? k_search_lane8_cols<true> : k_search_lane8_cols<false>, dim3((uint32_t)wgs), dim3(kColsThreads), 0,
+                               static_cast<hipStream_t>(stream), s, plan, rep);
+        }
         const int rc = (int)hipGetLastError();
         if (rc) return rc;
     }

@@ -51,8 +51,9 @@ __device__ __forceinline__ void search_chunks(const SearchArgs &a, uint32_t item
     // then serves the search rows that vertically adjacent blocks share
     const uint32_t wg = xcd_remap(blockIdx.x, total_wgs);
     const uint32_t nb = (uint32_t)a.grid.blocks();
-    // PRUNED starts optimistically in the centre row; ADAPTIVE lets the first chunk run exhaustively and judge
-    int start_row = 4, prune_pays = PRUNE && a.prune == 2 ? 0 : 1;
+    // ADAPTIVE lets the first chunk run exhaustively and judge; PRUNED prunes from the first chunk on: in the centre row
+    // under a predictor, otherwise in the row its first chunk votes for (start_row < 0: vote_start_row, aof_lane8.hpp)
+    int start_row = !PRUNE || a.pred ? 4 : -1, prune_pays = PRUNE && a.prune == 2 ? 0 : 1;
     int chunks_seen = 0, chunks_paying = 0;   // (PRUNE: what this wave reports, below)
     for (int c = 0; c < spw; c++) {
         const uint32_t item0 = (wg * (uint32_t)spw + (uint32_t)c) * blockDim.x;   // < 2^31 (launcher)

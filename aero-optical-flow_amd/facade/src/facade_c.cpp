@@ -1,5 +1,10 @@
 // Plain-C handles on the facade classes, so that non-C++ harnesses (the Python
 // tests via ctypes) drive the real C++ classes rather than a re-implementation.
+// Nothing throws across the C boundary: the classes are made with new (std::nothrow) -- a null handle
+// tells the caller, as /root/reference/src/mainloop.cpp:425-428 checks its own `new` -- and the one array
+// a delegate needs likewise.
+#include <new>
+
 #include "flow_opencv.hpp"
 #include "flow_px4.hpp"
 #include "optical_flow_rad.hpp"
@@ -9,14 +14,14 @@ extern "C" {
 void *aof_facade_px4_create(float fx, float fy, int output_rate, int w, int h, int search,
 			    int feature_threshold, int value_threshold)
 {
-	return new OpticalFlowPX4(fx, fy, output_rate, w, h, search, feature_threshold,
-				  value_threshold);
+	return new (std::nothrow) OpticalFlowPX4(fx, fy, output_rate, w, h, search, feature_threshold,
+						 value_threshold);
 }
 
 void *aof_facade_opencv_create(float fx, float fy, int output_rate, int w, int h)
 {
 	// exactly the five arguments /root/reference/src/mainloop.cpp:423-424 passes
-	return new OpticalFlowOpenCV(fx, fy, output_rate, w, h);
+	return new (std::nothrow) OpticalFlowOpenCV(fx, fy, output_rate, w, h);
 }
 
 void aof_facade_destroy(void *flow) { delete static_cast<OpticalFlow *>(flow); }
@@ -31,7 +36,8 @@ int aof_facade_px4_track_features(void *flow, const uint8_t *prev, const uint8_t
 {
 	// out6: capacity rows of {prev_x, prev_y, cur_x, cur_y, sad, accepted}
 	OpticalFlowPX4 *px4 = static_cast<OpticalFlowPX4 *>(flow);
-	TrackedFeature *tmp = new TrackedFeature[capacity > 0 ? capacity : 1];
+	TrackedFeature *tmp = new (std::nothrow) TrackedFeature[capacity > 0 ? capacity : 1];
+	if (!tmp) return -1;
 	int n = px4->trackFeatures(prev, cur, tmp, capacity);
 	for (int k = 0; k < n && k < capacity; k++) {
 		out6[6 * k + 0] = tmp[k].prev_x; out6[6 * k + 1] = tmp[k].prev_y;

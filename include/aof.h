@@ -162,6 +162,14 @@ typedef struct aof_search_stats {
     int32_t paying_pct;           /* share of the last report's chunks that left with "pruning pays" */
 } aof_search_stats;
 int aof_get_search_stats(const aof_ctx *ctx, aof_search_stats *out);
+/* What an ADAPTIVE 8x8 context believes about its images is learnt from its own launches, so a context that lives for
+ * ONE batch never uses it: its first launch lets every wave judge its first block exhaustively (6-10 % slower than either
+ * dedicated kernel).  Callers that know their footage -- from aof_get_search_stats of an earlier context over the same
+ * camera, or from the sensor -- say so here: 1 = pruning pays (launches prune from the first block on), 0 = it does not
+ * (the exhaustive kernel, with one pruned launch in 16 to look again), -1 = forget (judge again).  The context keeps
+ * learning from its launches afterwards.  Speed only: the records are the same.  The better cure is to create a
+ * context once and reuse it ("Batch callers"). */
+int aof_set_search_belief(aof_ctx *ctx, int belief);
 
 /* ---- the hot path, device-resident (batched) ----
  * d_prev/d_cur: device pointers, pair i at +i*pair_stride bytes, each frame
@@ -191,6 +199,19 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
  * keeps small batches (see aof_flow_batch_device) on the separate kernels as well. */
 int aof_set_split_coarse(aof_ctx *ctx, int on);
 
+/* Two-level batches whose coarse passes run as the fused kernel above (C3): the batch is cut into sub-batches and the
+ * coarse passes of sub-batch i + 1 run on a stream of the context's own BESIDE the level-0 search of sub-batch i on the
+ * caller's stream -- the coarse kernel holds one 512-lane workgroup per CU (LDS) and idles its VALU while it streams
+ * frames, the level-0 search is SAD issue and row-load latency, and the two share a CU where one after the other they
+ * add up.  The coarse stream is forked from and joined back into the caller's stream with events inside the call, so
+ * the call still only enqueues, is ordered like any other work on the caller's stream and can be captured into a
+ * hipGraph from it.  Records are the same bit for bit (every workspace region is written by exactly one sub-batch).
+ * pairs_per_sub_batch: < 0 (THE DEFAULT) = automatic: one workgroup of the coarse kernel per CU and enough blocks for
+ * the adaptive level-0 search to prune (256 pairs at VGA), batches of fewer than two sub-batches run in one pass;
+ * 0 = always one pass; > 0 = this many pairs per sub-batch (at most 16 sub-batches per call: larger batches get larger
+ * sub-batches). */
+int aof_set_coarse_overlap(aof_ctx *ctx, int64_t pairs_per_sub_batch);
+
 /* 8x8 tiles on grids of more than 256 blocks (C2, C3): the search kernel also reduces -- every wave adds
  * its votes to the pair's record in the CONTEXT's vote memory with integer atomics and the last wave
  * of a pair writes its aof_flow -- so no K3 launch follows (at 128 VGA pairs per call, configs[3]'s
@@ -208,8 +229,12 @@ int aof_set_split_coarse(aof_ctx *ctx, int on);
  * aof_stream_push_host on the context returns -EIO (aof_last_error names the pair).  The condition is
  * sticky, like a HIP fault: recover with a new context. */
 int aof_set_reduce_fusion(aof_ctx *ctx, int on);
-/* Test / diagnostic knob: the finaliser deadline above, in microseconds (default 50 000). */
+/* Diagnostic knob: the finaliser deadline above, in microseconds (default 50 000; at least 100, -EINVAL below:
+ * a deadline no launch can meet would disable the context with one call). */
 int aof_set_vote_deadline_us(aof_ctx *ctx, uint32_t microseconds);
+/* Fault injection for the tests of that path: the deadline in ticks of the 100 MHz counter, unchecked (0 = every
+ * finaliser gives up at once -> zero records, sticky -EIO). */
+int aof_debug_vote_deadline_ticks(aof_ctx *ctx, uint32_t ticks);
 
 /* ---- host-buffer conveniences (what the C++ facade calls) ----
  * Synchronous: copy in, run the kernels above, copy out.  blocks/subdirs may be NULL. */

@@ -478,8 +478,10 @@ def test_fused_coarse_kernel_at_vga_beyond_the_first_generation(aof, orc, synth,
 @pytest.mark.parametrize("kw", [dict(), dict(subpixel=1), dict(pyramid_levels=2, mean_subtract=1),
                                 dict(hist_filter=0, min_valid=3), dict(pyramid_levels=2, subpixel=1)])
 @pytest.mark.parametrize("shape", [(640, 480), (200, 150)])
-def test_reduction_inside_the_search_launch_equals_k3(aof, orc, synth, gpu_device, shape, kw):
-    """The flat lane8 search reduces in its own launch (votes through agent-scope atomics into the
+@pytest.mark.parametrize("mode", ["default", "pruned"])
+def test_reduction_inside_the_search_launch_equals_k3(aof, orc, synth, gpu_device, shape, kw, mode):
+    """(mode "pruned": the column walk of the pruned search, k_flow_lane8_cols, which votes block row by block row.)
+    The flat lane8 search reduces in its own launch (votes through agent-scope atomics into the
     context's vote memory, the last wave of a pair writes its flow record): flow records and block
     records byte-for-byte against the separate K3 launch and a sample against the oracle -- on common
     motions (two adds per wave), on mismatched frames (votes all over the histogram), gated and
@@ -500,6 +502,8 @@ def test_reduction_inside_the_search_launch_equals_k3(aof, orc, synth, gpu_devic
     cur = torch.from_numpy(hc[jdx]).to(gpu_device)
     eng = aof.FlowEngine(p, 0)
     assert eng.variant == "lane8"
+    if mode == "pruned":
+        eng.set_search_mode(aof.SEARCH_PRUNED)
     eng.set_reduce_fusion(False)
     b_ref, f_ref, _ = eng.flow_batch(prev, cur)
     torch.cuda.synchronize()
@@ -602,7 +606,9 @@ def test_a_finaliser_deadline_is_an_error_not_a_valid_flow(aof, synth, gpu_devic
     ref = aof.flows_view(f_ref)
     assert (ref["quality"] > 0).all()
     eng.set_reduce_fusion(True)
-    eng.set_vote_deadline_us(0)
+    with pytest.raises(aof.AofError):
+        eng.set_vote_deadline_us(0)       # a deadline no launch can meet is refused ...
+    eng.debug_vote_deadline_ticks(0)      # ... the fault injection is a call of its own
     _, flows, _ = eng.flow_batch(prev, cur)
     torch.cuda.synchronize()
     got = aof.flows_view(flows)
