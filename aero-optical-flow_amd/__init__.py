@@ -146,7 +146,6 @@ def _load():
         "aof_set_search_belief": (C.c_int, [VP, C.c_int]),
         "aof_set_split_coarse": (C.c_int, [VP, C.c_int]),
         "aof_set_reduce_fusion": (C.c_int, [VP, C.c_int]),
-        "aof_set_coarse_overlap": (C.c_int, [VP, I64]),
         "aof_flow_batch_device": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP, VP, C.c_size_t, VP]),
         "aof_flow_pair_host": (C.c_int, [VP, VP, VP, VP, VP, VP]),
         "aof_stream_push_host": (C.c_int, [VP, VP, VP]),
@@ -362,11 +361,6 @@ class FlowEngine:
         """Two-level batches: run K1 / level-1 search / level-1 reduce as separate kernels (fills the
         workspace's level-1 frames) instead of the fused coarse kernel."""
         self._check(lib.aof_set_split_coarse(self._ctx, int(on)))
-
-    def set_coarse_overlap(self, pairs_per_sub_batch=-1):
-        """Two-level batches served by the fused coarse kernel: pairs per sub-batch of the overlap of the coarse
-        passes of sub-batch i + 1 with the level-0 search of sub-batch i (0 = one pass, -1 = automatic, the default)."""
-        self._check(lib.aof_set_coarse_overlap(self._ctx, int(pairs_per_sub_batch)))
 
     def set_reduce_fusion(self, on=True):
         """8x8 tiles on large grids: on=True reduces inside the search launch (opt-in); the default

@@ -16,7 +16,6 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -24,8 +23,6 @@
 #include "aof_internal.hpp"
 
 using namespace aof;
-
-constexpr int kOverlapMaxSubs = 16;
 
 struct aof_ctx {
     aof_params params;
@@ -98,12 +95,6 @@ struct aof_ctx {
     hipEvent_t votes_done;      // recorded behind every launch that uses d_votes
     hipStream_t votes_stream;   // stream of that launch
     bool votes_used;
-    // two-level batches in sub-batches: the coarse passes of sub-batch i + 1 on a stream of the context's own, beside
-    // the level-0 search of sub-batch i on the caller's (aof_set_coarse_overlap; enqueue_overlapped)
-    int64_t overlap_pairs;      // pairs per sub-batch; 0 = one pass over the whole batch, < 0 = automatic
-    hipStream_t coarse_stream;
-    hipEvent_t overlap_fork;    // caller's stream -> coarse stream
-    hipEvent_t overlap_done[kOverlapMaxSubs];   // coarse passes of sub-batch i -> caller's stream
 };
 
 // Vote records per context (launches of more pairs keep K3).  2 048 finaliser waves are at most 256 per XCD --
@@ -277,8 +268,7 @@ constexpr int kProbeEvery = 16;
 bool adaptive_lane8_prunes(aof_ctx *ctx, const SearchArgs &a)
 {
     // level-1 searches and small launches: too few blocks per wave to carry a hint along
-    static const int64_t lab_min = std::getenv("AOF_LAB_PRUNE_MIN_CHUNKS") ? std::atoll(std::getenv("AOF_LAB_PRUNE_MIN_CHUNKS")) : kPruneMinChunks;   // LAB ONLY
-    if (a.level != 0 || !ctx->h_prune_slots || lane8_chunks(a) < lab_min) return false;
+    if (a.level != 0 || !ctx->h_prune_slots || lane8_chunks(a) < kPruneMinChunks) return false;
     if (ctx->prune_expected) {
         const uint32_t tag = ctx->prune_launch_no & 0xFFFFu;
         uint32_t arrived = 0, paying = 0, seen = 0;
@@ -518,66 +508,6 @@ int enqueue_fine(aof_ctx *ctx, const BatchView &v, int64_t first, int64_t n, hip
                          v.hist0 + (size_t)first * hist_bytes_per_pair(p, 0), AOF_K_SEARCH, AOF_K_REDUCE, s);
 }
 
-// Two-level batches whose coarse passes run as the fused kernel (C3): k_coarse keeps one 512-lane workgroup per CU --
-// two wave slots per SIMD stay free -- and spends a third of its time streaming frames with its VALU idle, while the
-// level-0 search is four waves per SIMD of SAD issue and row-load latency.  One after the other they add up; side by
-// side they share the CUs.  So the batch is cut into sub-batches and the coarse passes of sub-batch i + 1 run on the
-// context's own stream beside the level-0 search of sub-batch i on the caller's:
-//     caller's stream:  fork ............ wait(0) fine(0) wait(1) fine(1) ... wait(k) fine(k)
-//     coarse stream:    wait(fork) coarse(0) done(0) coarse(1) done(1) ... coarse(k) done(k)
-// The last wait joins the coarse stream back into the caller's (so the sequence can be captured into a hipGraph from
-// the caller's stream), the coarse stream runs ahead without ever waiting for the searches, and every region of the
-// workspace is written by exactly one sub-batch.  Pairs per sub-batch: 0 = one pass (no overlap).
-int64_t overlap_sub_batch(const aof_ctx *ctx, const BatchView &v, int64_t n_pairs)
-{
-    const aof_params &p = ctx->params;
-    if (!ctx->coarse_stream || ctx->overlap_pairs == 0 || p.pyramid_levels != 2 || ctx->force_generic || ctx->split_coarse ||
-        ctx->k1_ready)
-        return 0;
-    if (!coarse_fused_supported(coarse_args(ctx, v, 0, n_pairs, v.sums))) return 0;
-    // automatic: sub-batches of at least one workgroup of k_coarse per CU and enough 256-block chunks for the level-0
-    // search to prune (kPruneMinChunks), at most kOverlapMaxSubs of them, and nothing to overlap below two
-    int64_t sub = ctx->overlap_pairs;
-    if (sub < 0) {
-        sub = ctx->cus;
-        const int64_t prunes = (kPruneMinChunks * 256 + ctx->g0.blocks() - 1) / ctx->g0.blocks();
-        if (sub < prunes) sub = (prunes + ctx->cus - 1) / ctx->cus * ctx->cus;
-    }
-    if (sub * kOverlapMaxSubs < n_pairs) sub = (n_pairs + kOverlapMaxSubs - 1) / kOverlapMaxSubs;
-    return n_pairs >= 2 * sub ? sub : 0;
-}
-
-int enqueue_overlapped(aof_ctx *ctx, const BatchView &v, int64_t n_pairs, int64_t sub, hipStream_t s)
-{
-    hipStream_t cs = ctx->coarse_stream;
-    if (std::getenv("AOF_LAB_OVERLAP_SAME_STREAM")) {   // LAB ONLY: sub-batches one after the other on the caller's stream
-        int rc = 0;
-        for (int64_t first = 0; first < n_pairs && !rc; first += sub) {
-            const int64_t m = n_pairs - first < sub ? n_pairs - first : sub;
-            rc = enqueue_coarse(ctx, v, first, m, s);
-            if (!rc) rc = enqueue_fine(ctx, v, first, m, s);
-        }
-        return rc;
-    }
-    HIP_TRY(ctx, hipEventRecord(ctx->overlap_fork, s));
-    HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->overlap_fork, 0));
-    int rc = 0;
-    // (all coarse launches first: the host never stands between the coarse stream and its next kernel)
-    int k = 0;
-    for (int64_t first = 0; first < n_pairs && !rc; first += sub, k++) {
-        rc = enqueue_coarse(ctx, v, first, n_pairs - first < sub ? n_pairs - first : sub, cs);
-        if (!rc && hipEventRecord(ctx->overlap_done[k], cs) != hipSuccess) rc = fail(ctx, -EIO, "event record on the coarse stream");
-    }
-    // Whatever happened, the coarse stream joins the caller's again (a capture must not end with a stream left forked)
-    const int subs = k;
-    k = 0;
-    for (int64_t first = 0; first < n_pairs && k < subs; first += sub, k++) {
-        if (hipStreamWaitEvent(s, ctx->overlap_done[k], 0) != hipSuccess && !rc) rc = fail(ctx, -EIO, "event wait on the caller's stream");
-        if (!rc) rc = enqueue_fine(ctx, v, first, n_pairs - first < sub ? n_pairs - first : sub, s);
-    }
-    return rc;
-}
-
 // Views of one batch inside the caller's buffers and workspace.
 BatchView batch_view(const aof_ctx *ctx, const aof_ws_layout &L, const uint8_t *d_prev, const uint8_t *d_cur,
                      int64_t pair_stride, aof_block *d_blocks, uint8_t *d_subdirs, aof_flow *d_flows, void *d_workspace)
@@ -714,19 +644,6 @@ int aof_create(const aof_params *p, int device, aof_ctx **out)
         ctx->h_prune_slots = ctx->h_fault + 16;
         ctx->votes_pairs = kVotePairs;
     }
-    if (p->pyramid_levels == 2 && p->tile == 8 && p->search == 4) {
-        // the second stream and the events of the sub-batch overlap (made here: a call only enqueues, so that it can be captured)
-        DeviceGuard guard(device);
-        bool ok = hipStreamCreateWithFlags(&ctx->coarse_stream, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&ctx->overlap_fork, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; ok && i < kOverlapMaxSubs; i++)
-            ok = hipEventCreateWithFlags(&ctx->overlap_done[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            aof_destroy(ctx);
-            return -EIO;
-        }
-        ctx->overlap_pairs = 0;
-    }
     ctx->vote_deadline_ticks = kVoteDeadlineTicks;
     ctx->rstop_wait_s = 1.0;
     ctx->separate_reduce = true;   // the in-launch reduction is opt-in (aof_set_reduce_fusion)
@@ -755,7 +672,6 @@ void aof_destroy(aof_ctx *ctx)
     if (!leak && ctx->stream && (e = drain_bounded(ctx->stream, kDrainS)) != hipSuccess) leak = true;
     if (!leak && ctx->votes_done && ctx->votes_used && (e = event_wait_bounded(ctx->votes_done, kDrainS)) != hipSuccess)
         leak = true;
-    if (!leak && ctx->coarse_stream && (e = drain_bounded(ctx->coarse_stream, kDrainS)) != hipSuccess) leak = true;
     if (ctx->ev) {
         for (int k = 0; k < AOF_K_COUNT; k++)
             for (int r = 0; r < AOF_PROFILE_RING; r++)
@@ -784,9 +700,6 @@ void aof_destroy(aof_ctx *ctx)
     if (ctx->d_flow) (void)hipFree(ctx->d_flow);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->votes_done) (void)hipEventDestroy(ctx->votes_done);
-    if (ctx->coarse_stream) (void)hipStreamDestroy(ctx->coarse_stream);
-    if (ctx->overlap_fork) (void)hipEventDestroy(ctx->overlap_fork);
-    for (int i = 0; i < kOverlapMaxSubs; i++) if (ctx->overlap_done[i]) (void)hipEventDestroy(ctx->overlap_done[i]);
     if (ctx->d_votes) (void)hipFree(ctx->d_votes);
     if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     delete ctx;
@@ -962,7 +875,6 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
         }
     }
 
-    if (const int64_t sub = overlap_sub_batch(ctx, v, n_pairs)) return enqueue_overlapped(ctx, v, n_pairs, sub, s);
     rc = enqueue_coarse(ctx, v, 0, n_pairs, s);
     if (!rc) rc = enqueue_fine(ctx, v, 0, n_pairs, s);
     return rc;
@@ -1028,14 +940,6 @@ int aof_set_split_coarse(aof_ctx *ctx, int on)
     { DeviceGuard guard(ctx->device); (void)resident_stop(ctx); }   // it runs the kernels chosen so far
     if ((on != 0) != ctx->split_coarse) drop_push_graphs(ctx);
     ctx->split_coarse = on != 0;
-    return 0;
-}
-
-int aof_set_coarse_overlap(aof_ctx *ctx, int64_t pairs_per_sub_batch)
-{
-    if (!ctx) return -EINVAL;
-    if (!ctx->coarse_stream) return pairs_per_sub_batch == 0 ? 0 : fail(ctx, -EINVAL, "the context has no coarse passes to overlap (one level, or not 8x8 tiles over +-4)");
-    ctx->overlap_pairs = pairs_per_sub_batch;
     return 0;
 }
 

@@ -173,8 +173,8 @@ bool lane8_supported(const SearchArgs &a);
 bool lane8_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t capacity_pairs);
 int launch_search_lane8(const SearchArgs &a, void *stream, const FlowTail *tail = nullptr,
                         const VoteMem *votes = nullptr, PruneReport *report = nullptr);
-// 256-block chunks of the launch: the pruned kernel carries its hints from chunk to chunk of a workgroup and
-// needs a few thousand chunks before that pays (256 VGA pairs: +9 %, 512: +20 %, 1 024: +35 % on clean translations).
+// 256-block chunks of the launch: the pruned kernels carry their hints from block to block of a wave and need a
+// launch large enough for walks of three blocks before that pays (kPruneMinChunks below).
 int64_t lane8_chunks(const SearchArgs &a);
 // The pruned search on dense grids as a column walk (k_search_cols8.hip): a lane keeps the lower half of its window for
 // the block below.  Same modes (a.prune 1 / 2), same report.
@@ -183,7 +183,12 @@ bool lane8_cols_supported(const SearchArgs &a);
 bool lane8_cols_votes_supported(const SearchArgs &a, const VoteMem &votes, int64_t capacity_pairs);
 int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *report = nullptr, const FlowTail *tail = nullptr,
                              const VoteMem *votes = nullptr);
-constexpr int64_t kPruneMinChunks = 4096;
+// Smallest launch (in 256-block chunks) the ADAPTIVE mode lets prune.  Round 5 sweep, bench.py --pairs N as it chooses
+// itself (two batches in flight, graph replay), pruned column walk against the exhaustive kernel with the reduction in
+// its launch, us per step (profiles/r05_small_launch_prune_sweep.txt): 32 pairs 14.7 / 11.0, 64: 18.6 / 14.8,
+// 96: 22.2 / 20.4, 128: 23.0-24.5 / 26.0, 192: 26.6 / 38.0, 256: 33.8 / 49.7 -- a walk of two blocks pays for its vote
+// and its second round of row loads with too little; from three blocks on (112 VGA pairs) it wins.
+constexpr int64_t kPruneMinChunks = 2048;
 // Grids of 8..256 blocks: a workgroup owns whole pairs and also writes their flow records (no K3).
 int lane8_group(const SearchArgs &a);  // pairs per workgroup, 0 = not applicable
 int launch_flow_lane8(const SearchArgs &a, const FlowTail &tail, void *stream);

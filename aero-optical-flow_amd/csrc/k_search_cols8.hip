@@ -61,7 +61,7 @@ __device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &p
     //  kernel nothing -- 133.5 against 133.5 us per 1 024 VGA pairs.  Short segments for the launch's last pairs: c3's search
     //  kernel 180.8 -> 174.8 us, c2h's 227.7 -> 218.3, c2's 130.0 -> 128.7)
     const uint32_t wg = blockIdx.x;
-    const uint32_t unit0 = wg * kColsThreads + threadIdx.x;          // < 2^31 (launcher)
+    const uint32_t unit0 = wg * blockDim.x + threadIdx.x;            // < 2^31 (launcher)
     // the wave's segment class and pair, in scalar registers: units per pair are multiples of 64
     const bool in_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit0) >= plan.head_units;
     const ColsSegments sg = in_tail ? plan.tail : plan.head;
@@ -244,7 +244,7 @@ template <bool SUBPIXEL>
 __global__ __launch_bounds__(kColsThreads, 4) void k_flow_lane8_cols(SearchArgs a, ColsPlan plan, PruneReport report, ColsVotes cv)
 {
     if (blockIdx.x >= cv.search_wgs) {   // (uniform in the workgroup)
-        const uint32_t pair = (blockIdx.x - cv.search_wgs) * (kColsThreads >> 6) + (threadIdx.x >> 6);
+        const uint32_t pair = (blockIdx.x - cv.search_wgs) * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (pair < (uint32_t)a.n_pairs) await_votes_and_finalise(cv.votes, cv.tail, pair);
         return;
     }
@@ -303,7 +303,12 @@ int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *rep
         plan.head_pairs = (uint32_t)(s.n_pairs - tail_pairs);
         plan.head_units = plan.head_pairs * plan.head.units_per_pair;
         const int64_t units = (int64_t)plan.head_units + tail_pairs * plan.tail.units_per_pair;
-        const int64_t wgs = (units + kColsThreads - 1) / kColsThreads;
+        // a launch of one or two generations of waves ends sooner with one-wave workgroups, whose slots free up wave by
+        // wave for the other batch in flight (as flat_threads does for the exhaustive kernel, k_search_lane8.hip)
+        // (one-wave workgroups for launches of one or two generations of waves, as the exhaustive kernel has them, measure
+        //  the same within the spread of 200-step runs: profiles/r05_small_launch_shape.txt)
+        const int threads = kColsThreads;
+        const int64_t wgs = (units + threads - 1) / threads;
         PruneReport rep = {nullptr, 0, 1, 0};
         if (report && report->slots && done == 0) {
             rep = *report;
@@ -317,11 +322,11 @@ int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *rep
             cv.search_wgs = (uint32_t)wgs;
             cv.tail = *tail;
             cv.votes = *votes;
-            const int64_t finalisers = (s.n_pairs + (kColsThreads >> 6) - 1) / (kColsThreads >> 6);   // one wave per pair
+            const int64_t finalisers = (s.n_pairs + (threads >> 6) - 1) / (threads >> 6);   // one wave per pair
             hipLaunchKernelGGL(s.subpixel ? k_flow_lane8_cols<true> : k_flow_lane8_cols<false>, dim3((uint32_t)(wgs + finalisers)),
-                               dim3(kColsThreads), 0, static_cast<hipStream_t>(stream), s, plan, rep, cv);
+                               dim3(threads), 0, static_cast<hipStream_t>(stream), s, plan, rep, cv);
         } else {
-            hipLaunchKernelGGL(s.subpixel ? k_search_lane8_cols<true> : k_search_lane8_cols<false>, dim3((uint32_t)wgs), dim3(kColsThreads), 0,
+            hipLaunchKernelGGL(s.subpixel ? k_search_lane8_cols<true> : k_search_lane8_cols<false>, dim3((uint32_t)wgs), dim3(threads), 0,
                                static_cast<hipStream_t>(stream), s, plan, rep);
         }
         const int rc = (int)hipGetLastError();

@@ -560,10 +560,6 @@ def main():
     ap.add_argument("--coarse", default="auto", choices=["auto", "split"],
                     help="two-level workloads: how the coarse passes run -- auto (the fused kernel k_coarse where the "
                          "geometry allows) or split (K1 / level-1 search / K3 as separate kernels)")
-    ap.add_argument("--overlap", type=int, default=-1,
-                    help="two-level workloads: pairs per sub-batch of the library's own overlap of the coarse passes of "
-                         "sub-batch i + 1 with the level-0 search of sub-batch i (aof_set_coarse_overlap): -1 (default) = "
-                         "automatic, 0 = one pass over the whole batch")
     ap.add_argument("--reduce", default="auto", choices=["auto", "separate", "fused"],
                     help="separate: K3 behind the search; fused: the 8x8 search kernel reduces in its own launch "
                          "(votes through agent-scope atomics, finaliser waves behind the search); auto (default): "
@@ -753,8 +749,6 @@ def main():
             e.set_reduce_fusion(self.reduce_mode == "fused")
             if args.coarse != "auto":
                 e.set_split_coarse(True)
-            if args.overlap != -1 and p.pyramid_levels == 2 and p.tile == 8:
-                e.set_coarse_overlap(args.overlap)
 
         def set_profiling(self, on, kernels=None):
             self.profiling = bool(on)
@@ -910,8 +904,7 @@ def main():
         per_kernel["coarse_fused"] = per_kernel.pop("pyramid")
     per_kernel["step_in_this_pass"] = round(kpass_ms, 5)
     per_kernel["note"] = (f"one separate pass of {kpass} steps on lane 0 with HIP events around every kernel; step_in_this_pass is "
-                          "that pass's own wall time per step (the parts add up to less than it unless kernels of the step overlap: "
-                          "sub-batches of a two-level step run their coarse kernel beside the level-0 search); ms_per_step is authoritative")
+                          "that pass's own wall time per step: the parts add up to less than it; ms_per_step is authoritative")
     # ---- BASELINE configs[3] on every N > 1 line, whatever --scaling says: the STRONG shape ----
     # (--configs3-pairs, default 1 024, sharded over the ranks: 128 per GPU at N = 8, run as the automatic
     # choice runs it -- two lanes, graph replay, reduction in the search launch -- with the gather inside the

@@ -139,15 +139,17 @@ int aof_set_force_generic(aof_ctx *ctx, int on);
  *   16x16 tiles: a small probe kernel in front of the search computes the two-row bounds of a sample of every
  *   pair's blocks (1.6 % of them) and the search runs a pair's block rows pruned when the bounds predict that few
  *   candidates survive, exhaustively otherwise (the verdicts live in the workspace, aof_ws_layout.hints).
- *   8x8 tiles (level-0 searches of at least 4 096 x 256 blocks per launch; everything else runs EXHAUSTIVE): a
- *   probe per launch would cost more than it saves, so the CONTEXT learns from its own launches.  The pruned kernel -- whose waves run a chunk of blocks exhaustively, judge from its SADs whether
- *   rows could have been dropped, and prune the next chunks where they could -- reports the share of chunks that
- *   pruned (plain stores into pinned host memory, read at the next enqueue, never waited for).  While that share
- *   is at least 40 % the context keeps launching it (1 024 clean VGA translations: +40 % over EXHAUSTIVE, +20 % at
- *   +-8 LSB of noise); otherwise it launches the exhaustive kernel, and the pruned one once in 16 launches to look
- *   again (noise of +-16 LSB and more: within 1 % of EXHAUSTIVE, where PRUNED alone loses 12 %).  A context's first
- *   launch and a graph captured from it use whatever is known at that moment; half-pixel configurations prune too
- *   (+5 %).  aof_get_search_stats tells what happened. */
+ *   8x8 tiles (level-0 searches of at least 2 048 x 256 blocks per launch -- 112 VGA pairs --; everything else runs
+ *   EXHAUSTIVE): a probe per launch would cost more than it saves, so the CONTEXT learns from its own launches.  The
+ *   pruned kernel -- whose waves run a block exhaustively, judge from its SADs whether rows could have been dropped,
+ *   and prune the next blocks where they could -- reports the share of blocks that pruned (plain stores into pinned
+ *   host memory, read at the next enqueue, never waited for).  While that share is at least 40 % the context keeps
+ *   launching it, and its waves prune from their FIRST block on (which votes for the dy row to start in; round 5) --
+ *   1 024 VGA pairs per launch, same box (profiles/r05_final_c2_noise.txt): clean translations 1.55x EXHAUSTIVE, +-4 LSB
+ *   of noise 1.5x, +-8 LSB 1.2x --; otherwise it launches the exhaustive kernel, and the pruned one once in 16
+ *   launches to look again (+-16 LSB and more: within 2 % of EXHAUSTIVE, where PRUNED alone loses 12 %).  A context's
+ *   first launch and a graph captured from it use whatever is known at that moment (aof_set_search_belief tells a fresh
+ *   context); half-pixel configurations prune too.  aof_get_search_stats tells what happened. */
 #define AOF_SEARCH_EXHAUSTIVE 0
 #define AOF_SEARCH_PRUNED 1
 #define AOF_SEARCH_ADAPTIVE 2
@@ -198,19 +200,6 @@ int aof_flow_batch_device(aof_ctx *ctx, const uint8_t *d_prev, const uint8_t *d_
  * kernels K1 / K2 / K3 instead, which also fills l1_prev / l1_cur (tests compare the two), and
  * keeps small batches (see aof_flow_batch_device) on the separate kernels as well. */
 int aof_set_split_coarse(aof_ctx *ctx, int on);
-
-/* Two-level batches whose coarse passes run as the fused kernel above (C3): the batch is cut into sub-batches and the
- * coarse passes of sub-batch i + 1 run on a stream of the context's own BESIDE the level-0 search of sub-batch i on the
- * caller's stream -- the coarse kernel holds one 512-lane workgroup per CU (LDS) and idles its VALU while it streams
- * frames, the level-0 search is SAD issue and row-load latency, and the two share a CU where one after the other they
- * add up.  The coarse stream is forked from and joined back into the caller's stream with events inside the call, so
- * the call still only enqueues, is ordered like any other work on the caller's stream and can be captured into a
- * hipGraph from it.  Records are the same bit for bit (every workspace region is written by exactly one sub-batch).
- * pairs_per_sub_batch: < 0 (THE DEFAULT) = automatic: one workgroup of the coarse kernel per CU and enough blocks for
- * the adaptive level-0 search to prune (256 pairs at VGA), batches of fewer than two sub-batches run in one pass;
- * 0 = always one pass; > 0 = this many pairs per sub-batch (at most 16 sub-batches per call: larger batches get larger
- * sub-batches). */
-int aof_set_coarse_overlap(aof_ctx *ctx, int64_t pairs_per_sub_batch);
 
 /* 8x8 tiles on grids of more than 256 blocks (C2, C3): the search kernel also reduces -- every wave adds
  * its votes to the pair's record in the CONTEXT's vote memory with integer atomics and the last wave

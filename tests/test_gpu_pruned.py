@@ -377,7 +377,7 @@ def test_adaptive16_probe_on_narrow_tall_and_tiny_grids(aof, orc, synth, gpu_dev
 # ---- 8x8 tiles: AOF_SEARCH_ADAPTIVE, the default -- the context learns from its own launches which kernel to run ----
 
 def test_adaptive8_is_the_default_and_learns_from_its_own_launches(aof, orc, synth, gpu_device):
-    """A fresh 8x8 context searches in AOF_SEARCH_ADAPTIVE.  Launches of at least 4 096 chunks of 256 blocks go to the
+    """A fresh 8x8 context searches in AOF_SEARCH_ADAPTIVE.  Launches of at least 2 048 chunks of 256 blocks go to the
     pruned kernel (whose waves judge, chunk by chunk, whether rows could be dropped) while the kernel's own reports
     say that pruning pays, to the exhaustive kernel -- with one pruned launch in 16 to look again -- when they say
     it does not.  Whatever it picks, the records are the oracle's, byte for byte."""
