@@ -522,8 +522,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--settle-steps", type=int, default=500,
-                    help="untimed steps before the warm-up steps (clock settling under sustained load); 0 = off")
+    ap.add_argument("--settle-steps", type=int, default=-1,
+                    help="untimed steps before the warm-up steps (clock settling under sustained load); 0 = off; -1 (default) = "
+                         "as many as make about 0.2 s of load by the step's nominal work (1 024 VGA pairs: ~1 000 steps, 128 "
+                         "pairs: ~8 000: a 25 us step needs thousands of steps before the clocks have settled -- 200-step runs of "
+                         "the 128-pair step read 23 us, 2 000-step runs 19.3 us, profiles/r05_one_kernel_per_translation_unit_ab.txt); "
+                         "the number actually run is in the line (settle_steps)")
     ap.add_argument("--pairs", type=int, default=1024, help="frame pairs per GPU per step")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["ingest", "c1", "derotate", "seq"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
@@ -661,6 +665,13 @@ def main():
             reduce = "fused" if streams > 1 and n_pairs <= 512 else "separate"
         use_graph = graph == "on" or (graph == "auto" and launch_bound)
         return dict(streams=streams, reduce_mode=reduce, use_graph=use_graph, launch_bound=launch_bound)
+
+    def settle_steps_for(n_pairs):
+        """About 0.2 s of load, from the nominal work of a step alone (the same number on every rank)."""
+        if args.settle_steps >= 0:
+            return args.settle_steps
+        est_us = max(20.0, aof.abs_diffs(p) * n_pairs / 120e6)   # ~120 T abs-diffs/s: 1 024 VGA pairs ~ 200 us
+        return int(min(20000, max(200, 200000.0 / est_us)))
 
     cfg = auto_config(n, args.streams, args.reduce, args.graph)
     args.streams, reduce_mode, use_graph, launch_bound = cfg["streams"], cfg["reduce_mode"], cfg["use_graph"], cfg["launch_bound"]
@@ -838,7 +849,8 @@ def main():
     step, fence, drain = run.step, run.fence, run.drain
     eng_set_profiling = run.set_profiling
 
-    run.settle(args.settle_steps)   # (W is often only a handful of steps)
+    settle_n = settle_steps_for(n)
+    run.settle(settle_n)   # (W is often only a handful of steps)
     # HIP events around the dominant kernel (K2, level 0) on the launch stream.  Steps of a millisecond
     # or so carry them inside the timed region; every event pair costs the stream a few microseconds of
     # serialisation, so short steps (and replayed graphs, several lanes) are timed
@@ -925,7 +937,7 @@ def main():
         else:
             n3 = total3 // world
             c3 = auto_config(n3)
-            steps3 = args.steps
+            steps3 = max(args.steps, 1000)   # (a 20 us step: the timed region is a side leg of the line, long enough to be read)
             if args.scaling == "strong" and args.pairs == total3 and cfg == auto_config(n):
                 ms3 = elapsed / args.steps * 1e3   # the main region IS this shape
             else:
@@ -934,7 +946,7 @@ def main():
                 else:
                     prev3, cur3, _ = make_batch_gpu(W, H, n3, reach, 0xC3 + 7919 * rank, device, brightness=brightness)
                 r3 = Runner(prev3, cur3, c3["streams"], c3["reduce_mode"], c3["use_graph"], c3["launch_bound"], with_dist=True)
-                r3.settle(min(args.settle_steps, 200))
+                r3.settle(settle_steps_for(n3))
                 for _ in range(args.warmup):
                     r3.step()
                 ms3 = r3.timed(steps3) / steps3 * 1e3
@@ -949,7 +961,7 @@ def main():
                     prev1, cur1, _ = make_batch_gpu(W, H, total3, reach, 0xA0F, device, brightness=brightness)
                 c1 = auto_config(total3)
                 r1 = Runner(prev1, cur1, c1["streams"], c1["reduce_mode"], c1["use_graph"], c1["launch_bound"], with_dist=False)
-                r1.settle(min(args.settle_steps, 200))
+                r1.settle(settle_steps_for(total3))
                 for _ in range(args.warmup):
                     r1.step()
                 ms1 = r1.timed(steps3) / steps3 * 1e3
@@ -961,7 +973,7 @@ def main():
                 if args.search == "auto" and eng.variant == "lane8":
                     r1 = Runner(prev1, cur1, c1["streams"], c1["reduce_mode"], c1["use_graph"], c1["launch_bound"], with_dist=False,
                                 search="exhaustive")
-                    r1.settle(min(args.settle_steps, 200))
+                    r1.settle(settle_steps_for(total3))
                     for _ in range(args.warmup):
                         r1.step()
                     ms1x = r1.timed(steps3) / steps3 * 1e3
@@ -1006,7 +1018,7 @@ def main():
         "metric": f"frame-pairs/s ({W}x{H}, {p.tile}x{p.tile} SAD, +-{p.search} search)",
         "value": round(world * n * args.steps / elapsed, 1),
         "unit": "frame-pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle_steps,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_n,
         "ms_per_step": round(step_ms, 4),
         "timed_region_ms": round(elapsed * 1e3, 3),
         "timing_note": "ms_per_step = wall clock of the K timed steps between barrier + synchronize, / K: AUTHORITATIVE, value = pairs / it.  "
@@ -1112,7 +1124,7 @@ def main():
             if mode and not pruned_available:
                 continue
             rr = Runner(prev_r, cur_r, args.streams, reduce_mode, use_graph, launch_bound, with_dist=False, search=mode)
-            rr.settle(min(args.settle_steps, 300) if args.settle_steps else 0)
+            rr.settle(min(settle_n, 600))
             for _ in range(args.warmup):
                 rr.step()
             ms_r = rr.timed(args.steps) / args.steps * 1e3
@@ -1152,7 +1164,7 @@ def main():
                            ("c5", ["--workload", "c5", "--pairs", "256"]),
                            ("c5_realistic", ["--workload", "c5", "--pairs", "256", "--input", "realistic"])):
             cmd = [sys.executable, os.path.abspath(__file__)] + extra + [
-                "--steps", str(args.steps), "--warmup", str(args.warmup), "--settle-steps", str(min(args.settle_steps, 200)),
+                "--steps", str(args.steps), "--warmup", str(args.warmup), "--settle-steps", str(args.settle_steps if args.settle_steps >= 0 else 300),
                 "--cpu-seconds", "0", "--traffic", "file", "--legs", "none"]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
