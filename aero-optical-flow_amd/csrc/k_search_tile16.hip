@@ -107,6 +107,45 @@ __device__ __forceinline__ uint32_t eval_item(const uint8_t *s_prev, const uint8
     return row_key(acc, acc16, dyi);
 }
 
+// Staging of a block row: `total` 16-byte chunks, global memory -> LDS, `map(c, src, dst, is_cur)` names chunk c's addresses.
+// ALL of a lane's loads are issued before its first LDS write (eight in flight: the whole 60 KB tile of a 1280-pixel row is
+// on its way at once).  A plain copy loop compiles to load / s_waitcnt vmcnt(0) / ds_write per chunk -- one memory round
+// trip per 8 KB of the tile, seven or eight in a row, which is what the pruned search's workgroups spent most of their
+// time on (round 5: profiles/r05_tile16_staging.txt).  Lanes past the end load the last chunk again and drop it.
+// Only where the workgroup is short of work behind the staging: the pruned steps and the half-pixel refinement (c5h
+// 492 -> 435 us per 256 pairs, c5 365 -> 352, c5p 875 -> 833).  The exhaustive scan is bound by its SAD stream, its two
+// workgroups per CU overlap one's staging with the other's scan, and a tile that arrives all at once only puts them in
+// step: +3 % (706 -> 730 us) -- it keeps one chunk per lane in flight (kStageUnroll = 1).
+template <int kStageUnroll, typename Map>
+__device__ __forceinline__ void stage_chunks(int total, int tid, int delta, Map &&map)
+{
+    for (int c0 = tid; c0 < total; c0 += kStageUnroll * kThreads) {
+        uint4 v[kStageUnroll];
+#pragma unroll
+        for (int u = 0; u < kStageUnroll; u++) {
+            const int c = min(c0 + u * kThreads, total - 1);
+            const uint8_t *src;
+            uint8_t *dst;
+            bool is_cur;
+            map(c, src, dst, is_cur);
+            __builtin_memcpy(&v[u], src, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < kStageUnroll; u++) {
+            const int c = c0 + u * kThreads;
+            if (c < total) {
+                const uint8_t *src;
+                uint8_t *dst;
+                bool is_cur;
+                map(c, src, dst, is_cur);
+                uint4 w = v[u];
+                if (is_cur && delta != 0) w = sat_add_u8x16(w, delta);
+                *reinterpret_cast<uint4 *>(dst) = w;
+            }
+        }
+    }
+}
+
 // Appends the items of the wave's lanes that `keep` to a list in LDS, in lane order, with one
 // atomic per wave: neighbouring list entries stay neighbouring (dy, block) items, so the lanes
 // that later walk the list read neighbouring LDS windows like the exhaustive scan does (a list
@@ -141,6 +180,9 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     const int64_t pair = (int64_t)(logical / (uint32_t)ny);
     const int tid = threadIdx.x;
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * a.h));
+    // ADAPTIVE (a.prune == 2): the probe kernel in front of this launch has judged the pair (a.hints); PRUNED: always
+    typedef const __attribute__((address_space(4))) uint32_t *const_u32;   // (scalar load: uniform in the workgroup)
+    const bool pays = PRUNE && (a.prune != 2 || ((const_u32)a.hints)[pair] != 0u);
 
     // Level 0 under a predictor (px, py): the block row's windows move by py rows and px columns.
     // The cur rows are staged PRE-SHIFTED by px mod 16, so that LDS column c
@@ -181,49 +223,25 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         const int last_chunks = last_bytes / 16;
         const uint8_t *g_flat = g_cur - W, *g_last = g_cur + (int64_t)32 * W;
         uint8_t *s_flat = s_cur - W, *s_last = s_cur + (size_t)32 * W;
-        for (int c = tid; c < flat_chunks + last_chunks + prev_chunks; c += kThreads) {
-            const uint8_t *src;
-            uint8_t *dst;
-            bool is_cur = true;
+        stage_chunks<8>(flat_chunks + last_chunks + prev_chunks, tid, delta, [&](int c, const uint8_t *&src, uint8_t *&dst, bool &is_cur) {
+            is_cur = true;
             if (c < flat_chunks) { src = g_flat + (size_t)c * 16; dst = s_flat + (size_t)c * 16; }
             else if (c < flat_chunks + last_chunks) { src = g_last + (size_t)(c - flat_chunks) * 16; dst = s_last + (size_t)(c - flat_chunks) * 16; }
             else { is_cur = false; src = g_prev + (size_t)(c - flat_chunks - last_chunks) * 16; dst = s_prev + (size_t)(c - flat_chunks - last_chunks) * 16; }
-            uint4 v;
-            __builtin_memcpy(&v, src, 16);
-            if (is_cur && delta != 0) v = sat_add_u8x16(v, delta);
-            *reinterpret_cast<uint4 *>(dst) = v;
-        }
+        });
         const int odd = last_bytes - 16 * last_chunks;   // < 16 bytes of row 32, and the byte left of row -1
         if (tid < odd) s_last[16 * last_chunks + tid] = (uint8_t)clamp_u8((int)g_last[16 * last_chunks + tid] + delta);
         if (tid == 32 && rows_ok) s_flat[-1] = (uint8_t)clamp_u8((int)g_flat[-1] + delta);
-    } else if (org != 0 || sh != 0) {  // byte-aligned source: through registers
-        for (int c = tid; c < cur_chunks + prev_chunks; c += kThreads) {
-            const bool is_cur = c < cur_chunks;
+    } else {   // (a moved origin or a displaced row: byte-aligned sources; unaligned 16-byte loads all the same)
+        auto where = [&](int c, const uint8_t *&src, uint8_t *&dst, bool &is_cur) {
+            is_cur = c < cur_chunks;
             const int cc = is_cur ? c : c - cur_chunks;
-            uint4 v;
-            __builtin_memcpy(&v, (is_cur ? g_cur : g_prev) + (size_t)cc * 16, 16);
-            if (is_cur && delta != 0) {
-                v = sat_add_u8x16(v, delta);
-            }
-            *reinterpret_cast<uint4 *>((is_cur ? s_cur : s_prev) + (size_t)cc * 16) = v;
-        }
-    } else if (delta == 0) {
-        for (int c = tid; c < cur_chunks; c += kThreads)
-            *reinterpret_cast<uint4 *>(s_cur + (size_t)c * 16) =
-                *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
-    } else {
-        for (int c = tid; c < cur_chunks; c += kThreads) {
-            uint4 v = *reinterpret_cast<const uint4 *>(g_cur + (size_t)c * 16);
-            v = sat_add_u8x16(v, delta);
-            *reinterpret_cast<uint4 *>(s_cur + (size_t)c * 16) = v;
-        }
+            src = (is_cur ? g_cur : g_prev) + (size_t)cc * 16;
+            dst = (is_cur ? s_cur : s_prev) + (size_t)cc * 16;
+        };
+        if (PRUNE && pays) stage_chunks<8>(cur_chunks + prev_chunks, tid, delta, where);   // (uniform in the workgroup)
+        else stage_chunks<1>(cur_chunks + prev_chunks, tid, delta, where);
     }
-    if (org == 0 && sh == 0)
-        for (int c = tid; c < prev_chunks; c += kThreads) {
-            uint4 v;
-            __builtin_memcpy(&v, g_prev + (size_t)c * 16, 16);
-            *reinterpret_cast<uint4 *>(s_prev + (size_t)c * 16) = v;
-        }
     for (int b = tid; b < nx; b += kThreads) s_best[b] = 0xFFFFFFFFu;
     __syncthreads();
 
@@ -254,8 +272,6 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         // ADAPTIVE (a.prune == 2): the probe kernel in front of this launch has judged the pair (a.hints):
         // 0 = its candidates look alike (sensor noise: nothing could be dropped and the pruned steps would
         // cost 1.5x the exhaustive scan), so the workgroup runs the exhaustive scan; the records are the same.
-        typedef const __attribute__((address_space(4))) uint32_t *const_u32;   // (scalar load: uniform in the workgroup)
-        const bool pays = a.prune != 2 || ((const_u32)a.hints)[pair] != 0u;
         if (!pays) {
             for (int item = tid; item < items; item += kThreads) {
                 const int dyi = item / nx, bx = item - dyi * nx;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long differential fuzz on a GPU box (not part of the test suite): random geometry, options
-and image statistics; default, in-launch reduction, pruned, generic and separate-kernel device paths against the CPU oracle.
+and image statistics; default, in-launch reduction, pruned, pruned with the reduction in its launch, generic and separate-kernel
+device paths against the CPU oracle.
     python tools/fuzz_gpu.py [n_cases] [first_seed]            random configurations, two pairs per call
     python tools/fuzz_gpu.py [n_cases] [first_seed] many       the persistent coarse kernel: hundreds of pairs per call
     python tools/fuzz_gpu.py [n_cases] [first_seed] resident   the per-call path: resident kernel, tagged graph, eager launches
@@ -350,7 +351,7 @@ def main():
         small = small_eligible(p, aof.grid(p, 0), aof.grid(p, 1) if p.pyramid_levels == 2 else None)
         refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(n)]
         tp, tc = torch.from_numpy(prevs).to(dev), torch.from_numpy(curs).to(dev)
-        for mode in ("default", "exhaustive", "fused_reduce", "pruned", "generic", "split", "sequence_view"):
+        for mode in ("default", "exhaustive", "fused_reduce", "pruned", "pruned_fused_reduce", "generic", "split", "sequence_view"):
             if mode == "split" and p.pyramid_levels != 2 and not small:
                 continue   # (the separate kernels instead of k_coarse / k_flow_small)
             if mode == "default" and p.tile != 16:
@@ -382,6 +383,9 @@ def main():
             elif mode == "pruned":
                 eng.set_search_mode(aof.SEARCH_PRUNED)
             elif mode == "fused_reduce":
+                eng.set_reduce_fusion(True)
+            elif mode == "pruned_fused_reduce":   # (dense grids: the column walk that reduces in its launch, k_flow_lane8_cols)
+                eng.set_search_mode(aof.SEARCH_PRUNED)
                 eng.set_reduce_fusion(True)
             nb = eng.nblocks(0)
             # every output carved out of one arena with guard zones in between: a kernel that writes
@@ -447,11 +451,11 @@ def main():
             variants[name] = variants.get(name, 0) + 1
             eng.close()
         # 8x8 contexts on grids the flat kernel serves: the ADAPTIVE default on a launch large enough for the pruned kernel --
-        # the two pairs replicated, interleaved, to 4 096 chunks of 256 blocks and more --, three launches (nothing known yet:
+        # the two pairs replicated, interleaved, to 2 048 chunks of 256 blocks and more --, three launches (nothing known yet:
         # every wave's first chunk judges; then what the reports said), every replica against the oracle
         nb0 = aof.grid(p, 0)[4] * aof.grid(p, 0)[5]
         if p.tile == 8 and p.search == 4 and nb0 > 256 and rng.random() < 0.35:
-            reps = (4096 * 256 + n * nb0 - 1) // (n * nb0) + 1
+            reps = (2048 * 256 + n * nb0 - 1) // (n * nb0) + 1
             if 2 * reps * n * p.width * p.height <= (3 << 29):
                 eng = aof.FlowEngine(p, 0)
                 rp, rc = tp.repeat(reps, 1, 1).contiguous(), tc.repeat(reps, 1, 1).contiguous()
@@ -479,7 +483,7 @@ def main():
         done += 1
         if done % 25 == 0:
             print(f"{done} cases ok ({time.time() - t0:.0f} s), skipped {skipped}, kernels {variants}", flush=True)
-    print(f"fuzz passed: {done} cases x 6 device paths (+ the adaptive default on 16x16 cases, the separate kernels on two-level and "
+    print(f"fuzz passed: {done} cases x 7 device paths (+ the adaptive default on 16x16 cases, the separate kernels on two-level and "
           f"small-pair cases), {skipped} skipped, kernels {variants}, {time.time() - t0:.0f} s")
 
 
