@@ -17,6 +17,8 @@
 // lane-per-block kernels (aof_lane8_kernels.hpp says why).
 #pragma once
 
+#include <type_traits>
+
 #include "aof_cols8_plan.hpp"
 #include "aof_device.hpp"
 #include "aof_internal.hpp"
@@ -97,6 +99,8 @@ __device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &p
     // without one the first block votes for the row (vote_start_row, aof_lane8.hpp)
     int start_row = a.pred ? 4 : -1, prune_pays = a.prune == 2 ? 0 : 1;   // (wave-uniform: scalar registers)
     int seen = 0, paying = 0;
+    std::conditional_t<VOTE && !SUBPIXEL, WalkVotes, NoWalkVotes> pending;
+    pending.init();
     for (int step = 0; step < sg.len; step++) {
         const int by = by0 + step;
         const bool act = live && by < a.grid.ny;
@@ -187,7 +191,7 @@ __device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &p
             if constexpr (SUBPIXEL) dirs[slot] = (uint8_t)subdir;
         }
         if constexpr (VOTE) {
-            // a wave lies inside one pair: its blocks of this step vote and arrive with two or three atomics (one motion)
+            // a wave lies inside one pair: the steps of its walk that agree on the motion vote and arrive together (WalkVotes)
             const bool ok = act && (uint32_t)rec.sad < (uint32_t)a.value_threshold;   // skipped = 0xFFFF
             int hx = 0, hy = 0;
             if constexpr (SUBPIXEL) {
@@ -195,12 +199,15 @@ __device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &p
                 hy = (subdir == 1 || subdir == 2 || subdir == 3) ? 1 : ((subdir == 5 || subdir == 6 || subdir == 7) ? -1 : 0);
             }
             const int centre = 2 * a.hist_range + 1;
-            vote_and_arrive(*votes, a.hist_range, pair, act, ok, 2 * rec.dx + hx + centre, 2 * rec.dy + hy + centre);
+            // (the half-pixel walk sits at 128 VGPRs with nothing to spare for the pending votes: it adds step by step)
+            if constexpr (SUBPIXEL) vote_and_arrive(*votes, a.hist_range, pair, act, ok, 2 * rec.dx + hx + centre, 2 * rec.dy + hy + centre);
+            else pending.step(*votes, a.hist_range, pair, act, ok, 2 * rec.dx + hx + centre, 2 * rec.dy + hy + centre);
         }
         // the lower half of this window is the upper half of the next block's
 #pragma unroll
         for (int s = 0; s < 8; s++) win[s] = win[s + 8];
     }
+    if constexpr (VOTE) pending.flush(*votes, a.hist_range, pair);
     // one workgroup in report.stride tells the host how its first wave fared (aof_internal.hpp: PruneReport)
     if (report.slots && threadIdx.x == 0 && wg % report.stride == 0)
         __hip_atomic_store(report.slots + wg / report.stride, (report.launch_no << 16) | ((uint32_t)paying << 8) | (uint32_t)seen,

@@ -257,6 +257,69 @@ __device__ __forceinline__ void vote_and_arrive(const VoteMem &vm, int range, ui
                                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The same for a wave that WALKS several blocks per lane inside one pair (the column walk, aof_cols8_kernels.hpp): under a
+// global motion every step of the walk votes for the same pair of bins, so the wave keeps votes and arrivals of
+// consecutive steps that agree in scalar registers and adds them ONCE -- three atomics per walk instead of three per
+// step (eight steps per walk at 1 024 VGA pairs; with an add per step the kernel that reduces in its launch was 3 %
+// slower than search + K3, round 5).  A step whose motion differs flushes what is pending first; a step whose lanes
+// disagree among themselves votes at once, lane by lane, as vote_and_arrive does.  flush() behind the walk.
+struct NoWalkVotes {   // (the same walk without votes: nothing, so that it compiles to what it did)
+    __device__ __forceinline__ void init() {}
+    __device__ __forceinline__ void flush(const VoteMem &, int, uint32_t) {}
+    __device__ __forceinline__ void step(const VoteMem &, int, uint32_t, bool, bool, int, int) {}
+};
+struct WalkVotes {
+    int key;              // bins (x | y << 8) of the pending votes; only meaningful while votes != 0
+    uint32_t votes, arrivals;
+
+    __device__ __forceinline__ void init() { key = 0; votes = 0; arrivals = 0; }
+
+    __device__ __forceinline__ void flush(const VoteMem &vm, int range, uint32_t pair)
+    {
+        if (arrivals == 0) return;   // (wave-uniform; votes without arrivals do not exist)
+        const int n = 2 * (2 * range + 1) + 1;
+        uint32_t *rec = vm.base + (size_t)pair * vm.stride, *hist_x = rec + 2, *hist_y = rec + 2 + n;
+        if ((threadIdx.x & 63) == 0) {
+            if (votes) {
+                vote_add_agent(&hist_x[key & 0xFF], votes);
+                vote_add_agent(&hist_y[key >> 8], votes);
+            }
+            (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(rec), ((unsigned long long)arrivals << 32) | votes,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        votes = 0; arrivals = 0;
+    }
+
+    // one step of the walk, called by ALL 64 lanes; member / ok / bins as in vote_and_arrive
+    __device__ __forceinline__ void step(const VoteMem &vm, int range, uint32_t pair, bool member, bool ok, int bin_x, int bin_y)
+    {
+        const unsigned long long members = __ballot(member);
+        if (members == 0) return;   // (wave-uniform)
+        ok = ok && member;
+        const unsigned long long voters = __ballot(ok);
+        const uint32_t nm = (uint32_t)__popcll(members), nv = (uint32_t)__popcll(voters);
+        if (voters == 0) { arrivals = (uint32_t)__builtin_amdgcn_readfirstlane((int)(arrivals + nm)); return; }
+        const int mine = bin_x | (bin_y << 8);
+        const int k = __builtin_amdgcn_readlane(mine, __ffsll((long long)voters) - 1);   // scalar
+        if ((__ballot(ok && mine == k) & voters) == voters) {   // (wave-uniform) one motion in this step
+            if (votes != 0 && key != k) flush(vm, range, pair);
+            // (scalar registers: the walk's lanes sit at the 128 VGPRs of four waves per SIMD)
+            key = k;
+            votes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(votes + nv));
+            arrivals = (uint32_t)__builtin_amdgcn_readfirstlane((int)(arrivals + nm));
+            return;
+        }
+        flush(vm, range, pair);
+        const int n = 2 * (2 * range + 1) + 1;
+        uint32_t *rec = vm.base + (size_t)pair * vm.stride;
+        wave_vote_agent(rec + 2, bin_x, ok);
+        wave_vote_agent(rec + 2 + n, bin_y, ok);
+        if ((threadIdx.x & 63) == 0)
+            (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(rec), ((unsigned long long)nm << 32) | nv, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
 // Finaliser side: ONE WAVE per pair (all 64 lanes), n <= 62.  Gives up after vm.deadline_ticks of the
 // 100 MHz real-time counter (a search wave that never arrives means the launch is broken anyway): the
 // pair's flow record then says "nothing measured" -- flow 0, count 0, quality 0, NO valid flag -- and the
