@@ -1560,3 +1560,49 @@ def test_two_contexts_on_two_streams(aof, orc, synth, gpu_device):
     (ba, fa, _), (bb, fb, _) = outs[-1]
     check_against_oracle(aof, orc, pa, a_prev, a_cur, dict(blocks=aof.blocks_view(ba), flows=aof.flows_view(fa)))
     check_against_oracle(aof, orc, pb, b_prev, b_cur, dict(blocks=aof.blocks_view(bb), flows=aof.flows_view(fb)))
+
+
+@pytest.mark.gpu
+def test_wide_16x16_frames_keep_the_lds_tile_when_only_the_pruned_tables_do_not_fit(aof, orc, synth, gpu_device):
+    """at widths of about 3 000 pixels the pruned steps' tables (68 B per block column) push the 16x16 kernel's
+    LDS tile past 156 KB while the exhaustive tile still fits; the default (ADAPTIVE) context then runs the exhaustive
+    LDS kernel instead of dropping to the generic one."""
+    W, H = 3072, 64
+    p = aof.default_params(W, H, tile=16, search=8, value_threshold=12000, min_valid=0)
+    prevs, curs, _ = synth.make_batch(W, H, 2, 8, 9400, noise=2)
+    eng = aof.FlowEngine(p, 0)
+    assert eng.search_mode == aof.SEARCH_ADAPTIVE and eng.variant == "tile16_lds"
+    blocks, subdirs, flow = eng.flow_pair_host(prevs[0], curs[0])
+    ref = orc.flow_pair(orc.params_from(p), prevs[0], curs[0])
+    assert blocks.tobytes() == ref["blocks"].tobytes() and flow.tobytes() == ref["flow"].tobytes()
+    eng.force_generic(True)
+    b2, _, f2 = eng.flow_pair_host(prevs[0], curs[0])
+    assert b2.tobytes() == ref["blocks"].tobytes() and f2.tobytes() == ref["flow"].tobytes()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_a_faulted_context_launches_nothing_through_the_sequence_pipeline(aof, synth, gpu_device):
+    """aof_sequence_device checks the context's sticky state and the calling thread's device BEFORE its first
+    launch (the ingest kernel), and says why through aof_last_error."""
+    import torch
+    p = aof.default_params(640, 480)
+    hp, hc, _ = synth.make_batch(640, 480, 8, 4, 4300)
+    idx = np.arange(256) % 8
+    eng = aof.FlowEngine(p, 0)
+    eng.set_search_mode(aof.SEARCH_EXHAUSTIVE)
+    eng.set_reduce_fusion(True)
+    eng.debug_vote_deadline_ticks(0)
+    eng.flow_batch(torch.from_numpy(hp[idx]).to(gpu_device), torch.from_numpy(hc[idx]).to(gpu_device))
+    torch.cuda.synchronize()
+    frames = torch.full((4, 480, 640), 0x5A, dtype=torch.uint8, device=gpu_device)
+    times = torch.arange(4, dtype=torch.int64, device=gpu_device) * 40000
+    sp = aof.sequence_params(640, 480, 640, 480, 216.6677, 216.2457, 15, 5_000_000, 1, 100, 0)
+    L = aof.sequence_layout(p, sp, 4)
+    ws = torch.full((L.total_bytes,), 0xC3, dtype=torch.uint8, device=gpu_device)
+    with pytest.raises(aof.AofError) as e:
+        eng.sequence(sp, frames, times, workspace=ws)
+    assert e.value.code == -5 and "deadline" in str(e.value)
+    torch.cuda.synchronize()
+    assert bool((ws == 0xC3).all()), "the faulted context must not have launched anything into the workspace"
+    eng.close()

@@ -556,3 +556,85 @@ def test_adaptive8_launch_captured_into_a_graph(aof, orc, synth, gpu_device):
         assert eng.search_stats()["belief"] == 0, eng.search_stats()
         del g
         eng.close()
+
+
+# ---- round 5: start-row vote, launch-size threshold, belief hint, the column walk that reduces in its launch ----
+
+@pytest.mark.parametrize("shift", [(0, -4), (3, 4), (-4, 0), (1, -3), (-2, 2)])
+def test_pruned_walk_votes_for_its_start_row(aof, orc, synth, gpu_device, shift):
+    """AOF_SEARCH_PRUNED without a predictor: the first block of every walk votes for the dy row to start in
+    (vote_start_row) -- every dy row from the rim to the centre, on clean and noisy frames, one pair with a second
+    motion in its lower half (the vote is a majority, the search stays exact) and one whose votes tie."""
+    W, H = 320, 200
+    p = aof.default_params(W, H)
+    prevs, curs = [], []
+    for k, noise in enumerate((0, 6, 30)):
+        a, b, _ = synth.make_pair(W, H, 4, 9100 + k, shift=shift, noise=noise)
+        prevs.append(a); curs.append(b)
+    a, b, _ = synth.make_pair(W, H, 4, 9110, shift=shift)
+    _, b2, _ = synth.make_pair(W, H, 4, 9110, shift=(-shift[0], -shift[1]))
+    b = b.copy(); b[H // 2:] = b2[H // 2:]                       # two motions in one pair
+    prevs.append(a); curs.append(b)
+    both_modes_match_oracle(aof, orc, p, np.stack(prevs), np.stack(curs), gpu_device)
+
+
+def test_adaptive8_prunes_from_2048_chunks_on_and_takes_a_hint(aof, orc, synth, gpu_device):
+    """kPruneMinChunks = 2 048: a launch of 2 100 chunks prunes (round 4: 4 096), one of 1 900 does not; a fresh context
+    that is TOLD its images prune (aof_set_search_belief) starts every walk in the pruned code from its first launch
+    on, one told that they do not runs the exhaustive kernel -- the records are the oracle's either way."""
+    import torch
+    W, H, base = 192, 160, 4                       # 437 blocks per pair
+    p = aof.default_params(W, H)
+    po = orc.params_from(p)
+    prevs, curs, _ = synth.make_batch(W, H, base, 4, 9200, noise=1)
+    refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(base)]
+    for pairs, pruned in ((1232, 1), (1112, 0)):   # 2 103 / 1 898 chunks of 256 blocks
+        eng = aof.FlowEngine(p, 0)
+        blocks, flows, _ = eng.flow_batch(tiled(torch, prevs, pairs // base, gpu_device), tiled(torch, curs, pairs // base, gpu_device))
+        torch.cuda.synchronize()
+        assert replicas_equal(aof, blocks, flows, refs) < 0
+        st = eng.search_stats()
+        assert st["pruned_launches"] == pruned and st["exhaustive_launches"] == 1 - pruned, (pairs, st)
+        eng.close()
+    tp, tc = tiled(torch, prevs, 400, gpu_device), tiled(torch, curs, 400, gpu_device)
+    for belief, want in ((1, dict(pruned_launches=1, exhaustive_launches=0)), (0, dict(pruned_launches=0, exhaustive_launches=1))):
+        eng = aof.FlowEngine(p, 0)
+        eng.set_search_belief(belief)
+        assert eng.search_stats()["belief"] == belief
+        blocks, flows, _ = eng.flow_batch(tp, tc)
+        torch.cuda.synchronize()
+        assert replicas_equal(aof, blocks, flows, refs) < 0, belief
+        st = eng.search_stats()
+        assert {k: st[k] for k in want} == want, (belief, st)
+        eng.close()
+    eng = aof.FlowEngine(p, 0)
+    with pytest.raises(aof.AofError):
+        eng.set_search_belief(2)
+    eng.close()
+
+
+def test_column_walk_that_reduces_in_its_launch_on_a_large_adaptive_launch(aof, orc, synth, gpu_device):
+    """aof_set_reduce_fusion(1) on a context whose launches prune: k_flow_lane8_cols -- walks of several block rows whose
+    agreeing votes are added once (WalkVotes), walks whose motion changes half-way (flush), pairs without any vote --
+    flow records against K3's and the oracle's, over repeated launches (the vote memory is zero again after each)."""
+    import torch
+    W, H, base = 256, 208, 6                       # 31 x 25 = 775 blocks per pair
+    p = aof.default_params(W, H)
+    po = orc.params_from(p)
+    prevs, curs, _ = synth.make_batch(W, H, base, 4, 9300, noise=2)
+    _, other, _ = synth.make_batch(W, H, base, 4, 9300, noise=2, shift=(-3, 2))
+    curs[1, H // 3:] = other[1, H // 3:]           # the motion changes inside every column's walk
+    prevs[2] = 7                                   # flat: every block gated, arrivals without votes
+    rng = np.random.default_rng(3)
+    curs[3] = rng.integers(0, 256, curs[3].shape, dtype=np.uint8)   # unrelated: votes all over the histogram
+    refs = [orc.flow_pair(po, prevs[i], curs[i]) for i in range(base)]
+    reps = 120                                     # 720 pairs: 2 180 chunks, the launch prunes
+    tp, tc = tiled(torch, prevs, reps, gpu_device), tiled(torch, curs, reps, gpu_device)
+    eng = aof.FlowEngine(p, 0)
+    eng.set_reduce_fusion(True)
+    for launch in range(4):
+        blocks, flows, _ = eng.flow_batch(tp, tc)
+        torch.cuda.synchronize()
+        assert replicas_equal(aof, blocks, flows, refs) < 0, (launch, eng.search_stats())
+    assert eng.search_stats()["pruned_launches"] == 4
+    eng.close()

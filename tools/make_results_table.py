@@ -8,7 +8,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else "profiles/r04_final"
+prefix = sys.argv[1] if len(sys.argv) > 1 else "profiles/r05_final"
 order = ["c2", "c3", "c2h", "c5", "c5h", "c1b", "ingest", "derotate", "seq"]
 names = {"c2": "`c2` 640×480, 8×8 SAD, ±4, dense grid — the headline (exact-adaptive search, the default)", "c3": "`c3` = c2 + 2-level pyramid + mean equalisation",
          "c2h": "`c2h` = c2 + half-pixel refinement", "c5": "`c5` 1280×960, 16×16 SAD, ±8 (256 pairs per launch), exact-adaptive search",
@@ -31,8 +31,8 @@ def fmt_value(j):
 
 
 def results():
-    out = ["| workload (`bench.py --workload`) | throughput | step | whole step vs 8 TB/s | dominant kernel: time, vs 8 TB/s | beyond-L2 traffic / algorithmic | two batches in flight (`--streams 2`) | other search modes on the same batch | CPU oracle |",
-           "|---|---|---|---|---|---|---|---|---|"]
+    out = ["| workload (`bench.py --workload`) | throughput | step | whole step vs 8 TB/s | dominant kernel: time, vs 8 TB/s | beyond-L2 traffic / algorithmic | two batches in flight (`--streams 2`) | other search modes on the same batch | other inputs, default search: ±16 LSB noise; realistic (±4 LSB + half-pixel + half contrast) | CPU oracle |",
+           "|---|---|---|---|---|---|---|---|---|---|"]
     for w in order:
         j = load(w)
         if not j:
@@ -63,7 +63,12 @@ def results():
             ls = f"{fmt_value(l2)}"
             if l2["roofline"].get("frac_step"):
                 ls += f" (**{100*l2['roofline']['frac_step']:.1f} %**)"
-        out.append(f"| {names[w]} | {fmt_value(j)} | {step} | {fs} | {dom} | {tr} | {ls} | {prs} | {cbs} |")
+        ins = []
+        for tag in (w + "_noise16", w + "_realistic"):
+            k = load(tag)
+            ins.append(f"{k['value']/1e6:.2f} M ({100*k['roofline']['frac_step']:.1f} %)" if k else "—")
+        inp = f"{ins[0]}; {ins[1]}" if any(x != "—" for x in ins) else "—"
+        out.append(f"| {names[w]} | {fmt_value(j)} | {step} | {fs} | {dom} | {tr} | {ls} | {prs} | {inp} | {cbs} |")
     c1 = load("c1")
     if c1:
         c = c1["config"]
@@ -78,15 +83,18 @@ def results():
 def share():
     rows = [("share_p1024", "1 024 pairs, one batch in flight (the headline configuration: adaptive search, prunes)"),
             ("share_p1024_two_batches", "1 024 pairs, two batches in flight"),
-            ("share_p1024_exhaustive", "1 024 pairs, `--search exhaustive` (the search the 128-pair shares run), one batch in flight"),
+            ("share_p1024_exhaustive", "1 024 pairs, `--search exhaustive` (what every launch runs on inputs that do not prune), one batch in flight"),
             ("share_p1024_exhaustive_two_batches", "the same, two batches in flight"),
-            ("share_p512", "512 pairs (a 2-GPU share) as `bench.py --pairs 512` chooses: two batches in flight, pruned search + K3"),
-            ("share_p256", "256 pairs (a 4-GPU share), the same choice"),
-            ("share_p128_one_batch_separate", "128 pairs, one batch in flight, separate K3 (round 2's structure + the 1 024-lane K3, graph replay)"),
-            ("share_p128_one_batch_fused", "128 pairs, one batch in flight, reduction in the search launch"),
-            ("share_p128_two_batches_separate", "128 pairs, two batches in flight, separate K3"),
-            ("share_p128", "128 pairs, `bench.py --pairs 128` as it chooses itself: two batches in flight, graph replay, exhaustive search with the reduction in the launch"),
-            ("share_p128_eager", "the same, launched eagerly (`--graph off`)")]
+            ("share_p512", "512 pairs (a 2-GPU share) as `bench.py --pairs 512` chooses: one batch in flight, pruned search + K3"),
+            ("share_p256", "256 pairs (a 4-GPU share): two batches in flight, graph replay, pruned column walk with the reduction in its launch"),
+            ("share_p128", "**128 pairs, `bench.py --pairs 128` as it chooses itself**: two batches in flight, graph replay, adaptive search — since round 5 it prunes at this size — with the reduction in its launch (`k_flow_lane8_cols`)"),
+            ("share_p128_separate", "the same with K3 as a kernel of its own"),
+            ("share_p128_eager", "the same, launched eagerly (`--graph off`)"),
+            ("share_p128_one_batch", "128 pairs, one batch in flight"),
+            ("share_p128_exhaustive", "128 pairs, `--search exhaustive` with the reduction in the launch (round 4's choice at this size)"),
+            ("share_p128_noise16", "128 pairs on ±16 LSB of noise (the adaptive search settles on the exhaustive kernel)"),
+            ("share_p128_realistic", "128 pairs on the realistic input (the same)"),
+            ("share_p64", "64 pairs (a 16-GPU share; below the pruning threshold: exhaustive)")]
     base = load("share_p1024")
     if not base:
         return "(not collected)"
@@ -96,29 +104,31 @@ def share():
             return a if a["ms_per_step"] <= b["ms_per_step"] else b
         return a or b
     best = fastest("share_p1024", "share_p1024_two_batches")             # the fastest way one GPU runs the 1 024 pairs
-    same = fastest("share_p1024_exhaustive", "share_p1024_exhaustive_two_batches") or best   # ... with the shares' search
-    out = ["", "", "| step | time per step | pairs/s on one GPU | fastest 1 024-pair step with the SAME (exhaustive) search ÷ this step | fastest 1 024-pair step (adaptive search) ÷ this step |", "|---|---|---|---|---|"]
+    same = fastest("share_p1024_exhaustive", "share_p1024_exhaustive_two_batches") or best   # ... with the exhaustive search
+    out = ["", "", "| step | time per step | pairs/s on one GPU | 1 024-pair step, one batch in flight (what `configs3.vs_one_gpu_1024` compares with) ÷ this step | fastest 1 024-pair step (adaptive, two batches in flight) ÷ this step | fastest 1 024-pair step with the exhaustive search ÷ this step |", "|---|---|---|---|---|---|"]
     for tag, name in rows:
         j = load(tag)
         if not j:
             continue
-        r1, r2 = same["ms_per_step"] / j["ms_per_step"], best["ms_per_step"] / j["ms_per_step"]
+        r0, r1, r2 = base["ms_per_step"] / j["ms_per_step"], best["ms_per_step"] / j["ms_per_step"], same["ms_per_step"] / j["ms_per_step"]
         big = tag.startswith("share_p1024")
-        bold = tag == "share_p128"
-        out.append(f"| {name} | {j['ms_per_step']*1e3:.1f} µs | {j['value']/1e6:.2f} M | {'—' if big else (f'**{r1:.2f}×**' if bold else f'{r1:.2f}×')} | "
-                   f"{'—' if big else (f'**{r2:.2f}×**' if bold else f'{r2:.2f}×')} |")
-    j = load("share_p128")
+        b_ = lambda r, bold: "—" if big else (f"**{r:.2f}×**" if bold else f"{r:.2f}×")
+        out.append(f"| {name} | {j['ms_per_step']*1e3:.1f} µs | {j['value']/1e6:.2f} M | {b_(r0, tag == 'share_p128')} | {b_(r1, tag == 'share_p128')} | {b_(r2, tag in ('share_p128_noise16', 'share_p128_realistic', 'share_p128_exhaustive'))} |")
+    j, jn = load("share_p128"), load("share_p128_noise16")
     if j:
-        out += ["", f"Eight GPUs that each take 128 of the 1 024 pairs therefore finish a step in {j['ms_per_step']*1e3:.1f} µs.  One GPU that runs the SAME "
-                    f"exhaustive search on all of them takes {same['ms_per_step']*1e3:.1f} µs at its fastest: **{same['ms_per_step']/j['ms_per_step']:.1f}×** before the gather "
-                    "(16 KB per rank, asynchronous, overlapped with the next step), against the ≥ 6× `north_star` asks for.  Since round 4 one GPU with all "
-                    f"1 024 pairs in one launch does better than that — its adaptive search prunes: {best['ms_per_step']*1e3:.1f} µs — and the 128-pair shares cannot "
-                    f"follow (a pruning hint is carried from block to block of a wave, and 128 pairs leave the 4 096 wave slots two or three blocks each: the best pruned step measured at this size, 24.9 µs, beats the exhaustive one by 3 %): against THAT step "
-                    f"eight GPUs are {best['ms_per_step']/j['ms_per_step']:.1f}× faster.  The first figure is the scaling of the sharded job (the same computation on both sides); "
-                    "the second compares it with a faster single-GPU algorithm that needs launches of 256 pairs and more (a 4-GPU split of the 1 024 pairs still prunes: "
-                    f"{load('share_p256')['ms_per_step']*1e3:.1f} µs per 256-pair step).  `bench.py`'s N > 1 line reports both (`configs3.vs_one_gpu_1024_exhaustive`, `.vs_one_gpu_1024`).  "
-                    "With one batch in flight the 128-pair share is "
-                    "launch-bound (≈ 4.7 µs of every replayed graph are launch gaps, 5 µs the reduction): the two batches in flight are what the target needs."]
+        txt = (f"Eight GPUs that each take 128 of the 1 024 pairs finish a step in {j['ms_per_step']*1e3:.1f} µs (before the gather: 16 KB per rank, asynchronous, "
+               f"overlapped with the next step).  One GPU with all 1 024 pairs in one launch takes {base['ms_per_step']*1e3:.1f} µs with one batch in flight — "
+               f"**{base['ms_per_step']/j['ms_per_step']:.1f}×**, the figure `bench.py`'s N > 1 line reports as `configs3.vs_one_gpu_1024` — and "
+               f"{best['ms_per_step']*1e3:.1f} µs at its fastest (two batches in flight): **{best['ms_per_step']/j['ms_per_step']:.1f}×**, against the ≥ 6× `north_star` asks for.  "
+               "Round 4 stood at 5.2× here: its 128-pair shares could not prune (a wave walked two or three blocks and spent the first one judging exhaustively) while the "
+               "1 024-pair launch could.  Since round 5 the first block of a walk votes for its start row instead (108 SAD instructions against 432), launches prune from "
+               "2 048 chunks of 256 blocks on (112 VGA pairs), and the column walk reduces in its own launch.")
+        if jn:
+            txt += (f"  On inputs that do not prune both sides run the exhaustive kernel: {jn['ms_per_step']*1e3:.1f} µs per 128-pair step against "
+                    f"{same['ms_per_step']*1e3:.1f} µs for the 1 024 pairs: {same['ms_per_step']/jn['ms_per_step']:.1f}×.")
+        txt += ("  A 20 µs step is launch-bound with one batch in flight; the two batches in flight, the replayed graph and the reduction inside the search launch are what "
+                "the target needs, and 200-step runs of it read 10–15 % slow (the clocks settle over thousands of such steps: these lines time 2 000).")
+        out += ["", txt]
     return "\n".join(out)
 
 

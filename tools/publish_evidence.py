@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r05_final"
 ev, prof = os.path.join(ROOT, "gpurun_out", "evidence"), os.path.join(ROOT, "profiles")
 n = 0
 for f in sorted(glob.glob(os.path.join(ev, "bench_*.json"))):
@@ -34,6 +34,9 @@ if os.path.exists(nz):
             "# default (adaptive) search, and the exhaustive and the always-pruned search of the same batch timed behind it (records compared on the\n"
             "# device: identical); `adaptive stats` = aof_search_stats of the headline's context: which kernel its launches ran.\n")
     open(os.path.join(prof, f"{prefix}_c2_noise.txt"), "w").write(head + open(nz).read()); n += 1
+ab = os.path.join(ev, "ab_r04.txt")
+if os.path.exists(ab):
+    shutil.copy(ab, os.path.join(prof, f"{prefix}_ab_r04.txt")); n += 1
 src = os.path.join(ev, "pmc_traffic.json")
 if os.path.exists(src):
     new = json.load(open(src))

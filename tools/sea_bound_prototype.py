@@ -13,7 +13,8 @@ shape of k_search_lane8_cols:
     coarse block-sum bound,
 each with the visiting order of the kernel (start in the true row, outwards), and prices them in SAD-instruction
 equivalents against the exhaustive block (432 SAD instructions).  Numbers only; nothing here is shipped.
-usage: tools/sea_bound_prototype.py [pairs]
+usage: tools/sea_bound_prototype.py [pairs]      the bounds over sensor noise
+       tools/sea_bound_prototype.py --inputs     the shipped test on the components of bench.py --input realistic
 """
 import importlib.util, os, sys
 import numpy as np
@@ -82,7 +83,7 @@ def simulate(sad, bound_rows, partial=None):
 
 
 def main():
-    pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    pairs = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2
     print("noise | best SAD (median) | shipped partial-distortion: rows full / dropped@16px / dropped@32px -> SAD instr per block | "
           "row-sum bound: rows full -> instr | max(row,col)-sum bound: rows full -> instr | block-sum bound: rows full -> instr")
     for noise in (0, 4, 8, 16, 40):
@@ -107,5 +108,22 @@ def main():
     print("exhaustive block: 432 SAD instructions (+222 other VALU).  A bound pays at >= 1.2x only below ~360.")
 
 
+def inputs():
+    """What the shipped partial-distortion test can drop on the components of bench.py's "realistic" input, one pair each:
+    best and second-best SAD of a block (medians) and the rows a wave still sums completely."""
+    cases = {"clean": {}, "noise 4": dict(noise=4), "noise 8": dict(noise=8), "noise 16": dict(noise=16),
+             "half pixel (1,1)": dict(half=(1, 1)), "half pixel (1,0)": dict(half=(1, 0)), "contrast 0.8": dict(contrast=0.8),
+             "contrast 0.5": dict(contrast=0.5), "noise 4 + half pixel": dict(noise=4, half=(1, 1)),
+             "realistic (noise 4, half pixel, contrast 0.5)": dict(noise=4, half=(1, 1), contrast=0.5)}
+    for name, kw in cases.items():
+        prev, cur, _ = synth.make_pair(W, H, 4, 100, shift=(2, -1), **kw)
+        sad, _, _, _, p16, p32 = all_sads(prev, cur)
+        pd = simulate(sad, None, (p16, p32))
+        flat = np.sort(sad.reshape(NY, NX, -1), 2)
+        cost = 9 * (pd[0] * 48 + pd[1] * 14.25 + pd[2] * 28.5)
+        print(f"{name:46s} best SAD {np.median(flat[:, :, 0]):6.0f}  runner-up {np.median(flat[:, :, 1]):6.0f}  rows full {pd[0]:.3f}  "
+              f"dropped @16 px {pd[1]:.3f}  @32 px {pd[2]:.3f}  -> {cost:4.0f} SAD instructions per block (exhaustive 432)")
+
+
 if __name__ == "__main__":
-    main()
+    inputs() if "--inputs" in sys.argv else main()
