@@ -31,7 +31,7 @@ key_of() { case $1 in c5|c5h) echo 256;; c1b) echo 65536;; ingest) echo 8192;; d
 trace() {   # tag, bench arguments...: kernel-trace summary of one bench command
     tag=$1; shift
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -- python3 $R/bench.py "$@" --cpu-seconds 0 --legs none > $O/kt_$tag.log 2>&1 || { echo "kernel trace $tag failed"; tail -3 $O/kt_$tag.log; exit 1; }
-    python3 $R/tools/summarize_rocprof.py $(ls $O/kt_$tag/*/*kernel_stats.csv | head -1) "bench.py $* --cpu-seconds 0" | grep -v "at::native\|Memset\|elementwise\|Cijk\|rocprim\|vectorized" > $O/kernel_stats_$tag.txt
+    python3 $R/tools/summarize_rocprof.py $(ls $O/kt_$tag/*/*kernel_stats.csv | head -1) "bench.py $* --cpu-seconds 0 --legs none" | grep -v "at::native\|Memset\|elementwise\|Cijk\|rocprim\|vectorized" > $O/kernel_stats_$tag.txt
     rm -rf $O/kt_$tag
 }
 line() {   # tag, bench arguments...
