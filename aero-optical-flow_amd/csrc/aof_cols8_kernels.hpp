@@ -74,6 +74,32 @@ __device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &p
     uint32_t *const slots = reinterpret_cast<uint32_t *>(a.blocks) + (size_t)pair * (size_t)a.grid.blocks();
     uint8_t *const dirs = SUBPIXEL ? a.subdirs + (size_t)pair * (size_t)a.grid.blocks() : nullptr;
 
+    // Window rows under a predictor start at any byte (wx0 = 8 bx + px), and a 16-byte buffer load that is not dword-aligned
+    // costs the pruned search -- which waits for its row loads half of the time -- 30 % (C3, same box, every pair shifted
+    // alike: px = 0, 4, 8: 142 us per 1 024 pairs, every other px: 184 us; tools/lab/align_probe.py).  The misalignment is
+    // the same for every lane and row of a pair (rows are multiples of four bytes: plan.aligned, checked by the launcher).
+    // A misaligned pair loads its 16 bytes from the dword below (aligned), which leaves the last `mis` bytes out: they are the
+    // first bytes of dword 2 of the NEXT column's load (columns are eight bytes apart) -- one wave shift --, and the lanes
+    // without a next column in the wave (the row's last column, lane 63) fetch that dword themselves.
+    const uint32_t mis = plan.aligned ? (uint32_t)__builtin_amdgcn_readfirstlane(wx0 & 3) : 0u;   // (wave-uniform)
+    const bool lonely = (threadIdx.x & 63u) == 63u || bx + 1u == (uint32_t)a.grid.nx;
+    auto shifted_rows = [&](uint32_t off, uint4 *dst) {   // eight window rows from `off` on, through aligned loads
+        u32x4 v[8];
+        uint32_t e[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) v[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off - mis, s * W, 0);
+        if (lonely) {
+#pragma unroll
+            for (int s = 0; s < 8; s++) e[s] = __builtin_amdgcn_raw_buffer_load_b32(rs_cur, off - mis + 16u, s * W, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[s].z, 0x130, 0xF, 0xF, false);   // wave_shl:1: lane + 1's dword 2
+            const uint32_t tail = lonely ? e[s] : next;
+            dst[s] = make_uint4(__builtin_amdgcn_alignbyte(v[s].y, v[s].x, mis), __builtin_amdgcn_alignbyte(v[s].z, v[s].y, mis),
+                                __builtin_amdgcn_alignbyte(v[s].w, v[s].z, mis), __builtin_amdgcn_alignbyte(tail, v[s].w, mis));
+        }
+    };
     uint4 win[16];
     // the upper half of the segment's first window (every later block inherits its upper half from the block above).
     // Row bases: rows 0..7 are used only by a block that is searched (then wy0 >= 0), rows 8..15 also by the block below
@@ -82,7 +108,9 @@ __device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &p
     {
         const int wy0 = a.grid.y0 + by0 * a.grid.step_y + py - 4;
         const uint32_t off_cur = (uint32_t)(__mul24(wy0, W) + wx0);
-        if (live) {
+        if (mis != 0) {   // (scalar; every lane of the wave: the wave shift reads its neighbours)
+            shifted_rows(off_cur, win);
+        } else if (live) {
 #pragma unroll
             for (int s = 0; s < 8; s++) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off_cur, s * W, 0);
@@ -118,11 +146,16 @@ __device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &p
                 const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_prev, off_prev, r * W, 2);
                 ref[r][0] = v.x; ref[r][1] = v.y;
             }
+            if (mis == 0) {
 #pragma unroll
-            for (int s = 8; s < 16; s++) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off_cur8, (s - 8) * W, 0);
-                win[s] = make_uint4(v.x, v.y, v.z, v.w);
+                for (int s = 8; s < 16; s++) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off_cur8, (s - 8) * W, 0);
+                    win[s] = make_uint4(v.x, v.y, v.z, v.w);
+                }
             }
+        }
+        if (mis != 0 && __ballot(act) != 0) shifted_rows(off_cur8, win + 8);   // (every lane: the wave shift; rows of lanes that are not `act` are never used)
+        if (act) {
             asm volatile("" : "+v"(win[15].w));   // (one wait for all of the block's rows, in front of the gate)
         }
         if (act && delta != 0) {

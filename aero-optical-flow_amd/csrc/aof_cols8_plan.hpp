@@ -21,6 +21,7 @@ struct ColsPlan {
     ColsSegments head, tail;
     uint32_t head_pairs, head_units;   // head_units = head_pairs * head.units_per_pair
     FastDiv div_nx;
+    uint32_t aligned;                  // rows, pair strides and frame bases are multiples of four bytes (window_row)
 };
 // VOTE: the reduction in the same launch (aof_reduce.hpp: vote_and_arrive / await_votes_and_finalise, as in
 // k_flow_lane8_flat).  Workgroups [0, search_wgs) search and vote, the ones behind them are finalisers, one wave per pair.

@@ -41,6 +41,9 @@ int launch_search_lane8_cols(const SearchArgs &a, void *stream, PruneReport *rep
     plan.head = segments(len);
     plan.tail = segments(len / 2 < kColsMinRows ? kColsMinRows : len / 2);
     plan.div_nx = fastdiv_make((uint32_t)a.grid.nx);
+    // (columns eight bytes apart: every lane of a pair is misaligned alike and finds its last bytes in the next column's load)
+    plan.aligned = (a.grid.step_x == 8 && a.w % 4 == 0 && a.pair_stride % 4 == 0 && reinterpret_cast<uintptr_t>(a.cur) % 4 == 0 &&
+                    ((int64_t)a.w * a.h) % 4 == 0) ? 1u : 0u;
     const int64_t per = 0x7FFF0000ll / plan.tail.units_per_pair;   // pairs per launch: units are indexed with 31 bits
     for (int64_t done = 0; done < a.n_pairs; done += per) {
         SearchArgs s = a;
