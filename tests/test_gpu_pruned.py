@@ -638,3 +638,28 @@ def test_column_walk_that_reduces_in_its_launch_on_a_large_adaptive_launch(aof, 
         assert replicas_equal(aof, blocks, flows, refs) < 0, (launch, eng.search_stats())
     assert eng.search_stats()["pruned_launches"] == 4
     eng.close()
+
+
+@pytest.mark.parametrize("kw", [dict(pyramid_levels=2, mean_subtract=1), dict(pyramid_levels=2), dict(subpixel=1)])
+def test_column_walk_under_every_window_alignment(aof, orc, synth, gpu_device, kw):
+    """Round 5: a pair whose windows do not start on a dword (predictor px not a multiple of four; origin 5 of the half-pixel
+    grid) loads its window rows from the dword below and takes the missing bytes from the next column through a wave shift.
+    Every residue of px mod 4 with both signs, windows pushed to the left and right rim (columns that fall outside the frame,
+    a row's last column, lane 63 of a wave), the last pair of the batch (whose rows end where the arrays end), one and two
+    motions per pair -- pruned and exhaustive against the oracle."""
+    W, H = 656, 208                                   # 80 x 25 blocks: more than one wave per block row, lane 63 inside a row
+    p = aof.default_params(W, H, **kw)
+    two = p.pyramid_levels == 2
+    reach = 9 if two else 4
+    prevs, curs = [], []
+    shifts = list(range(-reach, reach + 1))
+    for k, sx in enumerate(shifts):
+        sy = (k * 5) % (2 * reach + 1) - reach
+        a, b, _ = synth.make_pair(W, H, reach, 9600 + k, shift=(sx, sy), noise=k % 3, brightness=6 if p.mean_subtract else 0)
+        prevs.append(a); curs.append(b)
+    a, b, _ = synth.make_pair(W, H, reach, 9650, shift=(reach - 2, -reach))
+    _, b2, _ = synth.make_pair(W, H, reach, 9650, shift=(-reach, reach - 1))
+    b = b.copy(); b[:, W // 2:] = b2[:, W // 2:]       # two motions side by side in the LAST pair
+    prevs.append(a); curs.append(b)
+    check = half_pixel_modes_match_oracle if p.subpixel else both_modes_match_oracle
+    check(aof, orc, p, np.stack(prevs), np.stack(curs), gpu_device)
