@@ -209,7 +209,9 @@ int aof_set_split_coarse(aof_ctx *ctx, int on);
  * ONE context must not overlap on the device: eager calls on different streams are ordered behind each
  * other by the library; captured graphs that contain calls on a context must not be replayed
  * concurrently with each other or with eager calls on it (once such a graph has been captured, the
- * library's own eager calls on the context keep to the separate K3).  Launches of more than 2 048 pairs
+ * library's own eager calls on the context keep to the separate K3).  Both forms of the search have it: the exhaustive
+ * scan (k_flow_lane8_flat) and, on dense grids, the pruned column walk (k_flow_lane8_cols, which adds the agreeing votes of
+ * a walk once); launches that prune on other grids keep K3.  Launches of more than 2 048 pairs
  * keep K3 as well.
  * on = 0 (THE DEFAULT): K3 runs as a separate kernel behind the search.  on = 1: opt in.
  * A finaliser wave that does not see its pair's votes complete within the deadline (50 ms; a launch in which
