@@ -97,6 +97,26 @@ __device__ __forceinline__ uint32_t row_key(const u64 (&acc)[4], uint32_t acc16,
     return best;
 }
 
+// The smallest of a dy row's 17 partial sums alone (the lower bounds of the pruned search need no candidate index): packed
+// minima instead of 17 keys -- 11 instructions against row_key's 25, on every (dy, block) item of every block row.
+typedef unsigned short ushort2_t16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t x, uint32_t y)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t16, x), __builtin_bit_cast(ushort2_t16, y)));
+}
+template <int NR, int STEP>
+__device__ __forceinline__ uint32_t bound_item(const uint8_t *s_prev, const uint8_t *s_cur, int W, int dyi, int bx, int xs,
+                                               int first, int delta = 0)
+{
+    u64 acc[4] = {0, 0, 0, 0};
+    uint32_t acc16 = 0;   // offset 16 in the high half
+    sum_item<NR, STEP>(s_prev, s_cur, W, dyi, bx, xs, first, acc, acc16, delta);
+    const uint32_t m01 = pk_min_u16(pk_min_u16((uint32_t)acc[0], (uint32_t)(acc[0] >> 32)), pk_min_u16((uint32_t)acc[1], (uint32_t)(acc[1] >> 32)));
+    const uint32_t m23 = pk_min_u16(pk_min_u16((uint32_t)acc[2], (uint32_t)(acc[2] >> 32)), pk_min_u16((uint32_t)acc[3], (uint32_t)(acc[3] >> 32)));
+    const uint32_t m = pk_min_u16(pk_min_u16(m01, m23), acc16 | 0xFFFFu);
+    return min(m & 0xFFFFu, m >> 16);
+}
+
 template <int NR, int STEP>
 __device__ __forceinline__ uint32_t eval_item(const uint8_t *s_prev, const uint8_t *s_cur, int W, int dyi, int bx, int xs,
                                               int first, int delta = 0)
@@ -121,26 +141,23 @@ __device__ __forceinline__ void stage_chunks(int total, int tid, int delta, Map 
 {
     for (int c0 = tid; c0 < total; c0 += kStageUnroll * kThreads) {
         uint4 v[kStageUnroll];
+        uint8_t *to[kStageUnroll];       // (LDS: one register each; kept from the address pass, not computed twice)
+        bool shift[kStageUnroll];
 #pragma unroll
         for (int u = 0; u < kStageUnroll; u++) {
             const int c = min(c0 + u * kThreads, total - 1);
             const uint8_t *src;
-            uint8_t *dst;
             bool is_cur;
-            map(c, src, dst, is_cur);
+            map(c, src, to[u], is_cur);
+            shift[u] = is_cur && delta != 0;
             __builtin_memcpy(&v[u], src, 16);
         }
 #pragma unroll
         for (int u = 0; u < kStageUnroll; u++) {
-            const int c = c0 + u * kThreads;
-            if (c < total) {
-                const uint8_t *src;
-                uint8_t *dst;
-                bool is_cur;
-                map(c, src, dst, is_cur);
+            if (c0 + u * kThreads < total) {
                 uint4 w = v[u];
-                if (is_cur && delta != 0) w = sat_add_u8x16(w, delta);
-                *reinterpret_cast<uint4 *>(dst) = w;
+                if (shift[u]) w = sat_add_u8x16(w, delta);
+                *reinterpret_cast<uint4 *>(to[u]) = w;
             }
         }
     }
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     const int items = rows_ok ? kSide * nx : 0;
     if constexpr (!PRUNE) {
         for (int item = tid; item < items; item += kThreads) {
-            const int dyi = item / nx, bx = item - dyi * nx;
+            const int dyi = (int)fast_div((uint32_t)item, a.div_nx), bx = item - dyi * nx;
             const int xf = 16 * bx + px;                  // moved-frame column of the window start
             if (xf < 0 || xf + 32 > Wb) continue;         // window leaves the frame: block skipped below
             atomicMin(&s_best[bx], eval_item<16, 1>(s_prev, s_cur, W, dyi, bx, xf - sh, 0));
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         // cost 1.5x the exhaustive scan), so the workgroup runs the exhaustive scan; the records are the same.
         if (!pays) {
             for (int item = tid; item < items; item += kThreads) {
-                const int dyi = item / nx, bx = item - dyi * nx;
+                const int dyi = (int)fast_div((uint32_t)item, a.div_nx), bx = item - dyi * nx;
                 const int xf = 16 * bx + px;
                 if (xf < 0 || xf + 32 > Wb) continue;
                 atomicMin(&s_best[bx], eval_item<16, 1>(s_prev, s_cur, W, dyi, bx, xf - sh, 0));
@@ -283,10 +300,10 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         const int items_all = items;
         const int items = pays ? items_all : 0;   // (the pruned steps below then have nothing to do)
         for (int item = tid; item < items; item += kThreads) {
-            const int dyi = item / nx, bx = item - dyi * nx;
+            const int dyi = (int)fast_div((uint32_t)item, a.div_nx), bx = item - dyi * nx;
             const int xf = 16 * bx + px;
             uint32_t bound = 0xFFFFu;
-            if (!(xf < 0 || xf + 32 > Wb)) bound = eval_item<kBoundRows, 16 / kBoundRows>(s_prev, s_cur, W, dyi, bx, xf - sh, 8 / kBoundRows) >> 16;
+            if (!(xf < 0 || xf + 32 > Wb)) bound = bound_item<kBoundRows, 16 / kBoundRows>(s_prev, s_cur, W, dyi, bx, xf - sh, 8 / kBoundRows);
             s_pmin[item] = (uint16_t)bound;
         }
         __syncthreads();
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
             const int item = item0 + (tid & 63);
             bool keep = false;
             if (item < items) {
-                const int dyi = item / nx, bx = item - dyi * nx;
+                const int dyi = (int)fast_div((uint32_t)item, a.div_nx), bx = item - dyi * nx;
                 const uint32_t bound = s_pmin[item];
                 keep = bound != 0xFFFFu && bound <= (s_best[bx] >> 16);
             }
@@ -353,8 +370,8 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
                 item = s_list[k];
                 keep = true;
                 if (bound_pays) {
-                    const int dyi = item / nx, bx = item - dyi * nx;
-                    const uint32_t bound = eval_item<4, 4>(s_prev, s_cur, W, dyi, bx, 16 * bx + px - sh, 1) >> 16;
+                    const int dyi = (int)fast_div((uint32_t)item, a.div_nx), bx = item - dyi * nx;
+                    const uint32_t bound = bound_item<4, 4>(s_prev, s_cur, W, dyi, bx, 16 * bx + px - sh, 1);
                     keep = bound <= (s_best[bx] >> 16);
                 }
             }
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         const int listed2 = (int)*s_count;
         for (int k = tid; k < listed2; k += kThreads) {
             const int item = s_list2[k];
-            const int dyi = item / nx, bx = item - dyi * nx;
+            const int dyi = (int)fast_div((uint32_t)item, a.div_nx), bx = item - dyi * nx;
             atomicMin(&s_best[bx], eval_item<16, 1>(s_prev, s_cur, W, dyi, bx, 16 * bx + px - sh, 0));
         }
     }
@@ -479,8 +496,8 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
         const int xf = 16 * bx + px, yc0 = 16 * by + py;
         uint32_t bound = 0xFFFFu;
         if (xf >= 0 && xf + 32 <= Wb && yc0 >= 0 && yc0 + 32 <= H)
-            bound = eval_item<kBoundRows, 16 / kBoundRows>(prev + (int64_t)(16 * by + 8) * W + 8, cur + (int64_t)yc0 * W, W, dyi, bx, xf,
-                                                           8 / kBoundRows, delta) >> 16;
+            bound = bound_item<kBoundRows, 16 / kBoundRows>(prev + (int64_t)(16 * by + 8) * W + 8, cur + (int64_t)yc0 * W, W, dyi, bx, xf,
+                                                            8 / kBoundRows, delta);
         s_bound[blk][dyi] = (uint16_t)bound;
     }
     __syncthreads();
@@ -547,6 +564,8 @@ int launch_search_tile16(const SearchArgs &a, void *stream)
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
+    SearchArgs k = a;
+    k.div_nx = fastdiv_make((uint32_t)a.grid.nx);   // item -> (dy row, block): a run-time division costs ~20 VALU per lane and item
     const size_t lds = tile16_lds(a);
     void (*fn)(SearchArgs, uint32_t) =
         tile16_refines(a) ? (a.prune ? k_search_tile16<true, true> : k_search_tile16<false, true>)
@@ -556,7 +575,7 @@ int launch_search_tile16(const SearchArgs &a, void *stream)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(fn, dim3((uint32_t)total), dim3(kThreads), lds, static_cast<hipStream_t>(stream), a,
+    hipLaunchKernelGGL(fn, dim3((uint32_t)total), dim3(kThreads), lds, static_cast<hipStream_t>(stream), k,
                        (uint32_t)total);
     return (int)hipGetLastError();
 }
