@@ -75,7 +75,7 @@ __device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &p
     uint8_t *const dirs = SUBPIXEL ? a.subdirs + (size_t)pair * (size_t)a.grid.blocks() : nullptr;
 
     // Window rows under a predictor start at any byte (wx0 = 8 bx + px), and a 16-byte buffer load that is not dword-aligned
-    // costs the pruned search -- which waits for its row loads half of the time -- 30 % (C3, same box, every pair shifted
+    // costs the pruned search -- whose four waves per SIMD just about cover the aligned loads -- 30 % (C3, same box, every pair shifted
     // alike: px = 0, 4, 8: 142 us per 1 024 pairs, every other px: 184 us; tools/lab/align_probe.py).  The misalignment is
     // the same for every lane and row of a pair (rows are multiples of four bytes: plan.aligned, checked by the launcher).
     // A misaligned pair loads its 16 bytes from the dword below (aligned), which leaves the last `mis` bytes out: they are the

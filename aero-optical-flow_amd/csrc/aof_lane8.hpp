@@ -94,7 +94,7 @@ __device__ __forceinline__ uint32_t exhaustive_search(const uint4 (&win)[16], co
 
 // The exhaustive scan of the PRUNED kernel, dy row by dy row: five accumulator registers live instead of the 45 of
 // exhaustive_search, so that this path does not set the kernel's register allocation (122 VGPRs = four waves per SIMD,
-// which the kernel needs: on images that prune, half of a wave's time is waiting for its row loads).  Besides the best key
+// which the kernel needs to cover its row loads on images that prune: LAB_LOG.md, round 5).  Besides the best key
 // it says how many of the nine dy rows the pruned code would PROBABLY have dropped for the whole wave: a row whose
 // smallest SAD, scaled to what pruned_row's tests see of it, lies above every needing lane's best.  A guess about
 // speed only (it picks the code that evaluates the wave's NEXT chunk); the keys are the exhaustive ones.
