@@ -8,10 +8,12 @@
 //   phase 1  streams the pair's two frames once (16 B per lane from two adjacent rows, many loads
 //            in flight), box-filters them into LDS and sums the level-0 / level-1 bytes;
 //   phase 2  equalises the level-1 `cur` frame in place (each pixel once, not once per window);
-//   phase 3  gates every block (4x4 gradient) and searches: one lane per (block, dy row) item,
+//   phase 3  gates every block (4x4 gradient) and searches: one lane per (block, three dy rows) item,
 //            dy-major, so a wave reads 64 neighbouring windows of one row -- conflict-free
-//            ds_read_b64 -- and 9 * nb items fill 512 lanes to 99 %; the nine dy rows of a block
-//            meet in an LDS atomicMin on the packed key (sad << 16 | idx) = first minimum wins;
+//            ds_read_b64 --; three neighbouring dy rows share ten window rows and the tile (28 reads
+//            where three one-row items made 72; round 5: 168 -> 157 us per 1 024 VGA pairs), 3 * nb
+//            items fill 512 lanes to 95 %; the three items of a block meet in an LDS atomicMin on
+//            the packed key (sad << 16 | idx) = first minimum wins;
 //   phase 4  writes the level-1 records, votes, and wave 0 finalises the predictor -- while the other
 //            waves already stream the workgroup's next pair (two sets of histograms take turns).
 // HBM traffic: the frames once, 4.5 KB of records and 16 B of predictor per pair.
@@ -30,9 +32,9 @@ namespace aof {
 
 namespace {
 
-// 512 lanes = two waves per SIMD (127 VGPRs): alone the kernel is as fast as with 1 024 lanes (171 us against
-// 174 us per 1 024 VGA pairs), and it leaves half of the CU's registers and wave slots to the level-0
-// search waves of ANOTHER batch in flight (bench.py --streams 2: 407 -> 398 us per C3 step, round 3)
+// 512 lanes = two waves per SIMD (148 VGPRs since the search sums three dy rows per lane): alone the kernel is as fast
+// as with 1 024 lanes (171 us against 174 us per 1 024 VGA pairs, round 3), and it leaves 216 of a SIMD's 512 registers
+// and two wave slots to the level-0 search waves of ANOTHER batch in flight (bench.py --streams 2)
 constexpr int kThreads = 512;
 constexpr int kUnroll = 4;            // sweeps per batch; two batches = 16 loads of 16 B in flight per lane
 constexpr uint32_t kGated = 0xFFFFFFFEu;   // key of a block the gradient gate rejected
@@ -230,40 +232,59 @@ __global__ __launch_bounds__(kThreads) void k_coarse(CoarseArgs a)
     lds_barrier();
     AOF_LAB_STAMP(pair, 2);
 
-    // ---- phase 3: one lane per (dy row, block) item ----
-    const int items = 9 * nb;
+    // ---- phase 3: one lane per (three dy rows, block) item ----
+    // Three neighbouring dy rows of a block share ten window rows and the tile: 28 eight-byte LDS reads for 144 SAD
+    // instructions where three single-row items read 72 -- the phase is as much LDS reads, index arithmetic and keys as it is
+    // SAD issue.  3 * nb items fill 512 lanes to 95 % (9 * nb single rows: 99 %).
+    const int items = 3 * nb;
     for (int item = tid; item < items; item += kThreads) {
         // (everything below 2^24: full-rate 24-bit multiplies instead of quarter-rate 32-bit ones)
-        const int d = (int)fast_div((uint32_t)item, a.div_nb), blk = item - __mul24(d, nb);
+        const int t = (int)fast_div((uint32_t)item, a.div_nb), blk = item - __mul24(t, nb);
         if (keys[blk] == kGated) continue;
+        const int d0 = 3 * t;
         const int by = (int)fast_div((uint32_t)blk, a.div_nx), bx = blk - __mul24(by, a.grid.nx);
         const uint8_t *ref = l1[0] + __mul24(y0 + 8 * by, w1) + x0 + 8 * bx;
-        const uint8_t *win = l1[1] + __mul24(y0 + 8 * by - 4 + d, w1) + (x0 - 4) + 8 * bx;   // 8-byte aligned
-        u64 lo = 0, hi = 0;
-        uint32_t a8 = (uint32_t)(d * 9 + 8);
+        const uint8_t *win = l1[1] + __mul24(y0 + 8 * by - 4 + d0, w1) + (x0 - 4) + 8 * bx;   // 8-byte aligned
+        uint32_t tile[8][2];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(ref + r * w1);
-            const uint32_t r0 = q[0], r1 = q[1];
-            const uint2 wa = *reinterpret_cast<const uint2 *>(win + r * w1);
-            const uint2 wb = *reinterpret_cast<const uint2 *>(win + r * w1 + 8);
-            const u64 p01 = pack64(wa.x, wa.y), p12 = pack64(wa.y, wb.x), p23 = pack64(wb.x, wb.y);
-            lo = qsad(p01, r0, lo);
-            lo = qsad(p12, r1, lo);
-            hi = qsad(p12, r0, hi);
-            hi = qsad(p23, r1, hi);
-            a8 = __builtin_amdgcn_sad_hi_u8(wb.x, r0, a8);
-            a8 = __builtin_amdgcn_sad_hi_u8(wb.y, r1, a8);
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(ref + r * w1);   // (x0 = 4: 4-byte aligned)
+            tile[r][0] = q[0]; tile[r][1] = q[1];
         }
-        const uint32_t base = (uint32_t)(d * 9);
-        const uint32_t l0 = (uint32_t)lo, l1w = (uint32_t)(lo >> 32), h0 = (uint32_t)hi, h1w = (uint32_t)(hi >> 32);
-        const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
-        const uint32_t k2 = (l1w << 16) | (base + 2), k3 = (l1w & 0xFFFF0000u) | (base + 3);
-        const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
-        const uint32_t k6 = (h1w << 16) | (base + 6), k7 = (h1w & 0xFFFF0000u) | (base + 7);
-        uint32_t best = min(min(k0, k1), k2);
-        best = min(best, min(min(k3, k4), k5));
-        best = min(best, min(min(k6, k7), a8));
+        u64 lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        uint32_t a8[3];
+#pragma unroll
+        for (int dd = 0; dd < 3; dd++) a8[dd] = (uint32_t)((d0 + dd) * 9 + 8);
+#pragma unroll
+        for (int j = 0; j < 10; j++) {   // window row j of the triple: tile row j - dd of dy row d0 + dd
+            const uint2 wa = *reinterpret_cast<const uint2 *>(win + j * w1);
+            const uint2 wb = *reinterpret_cast<const uint2 *>(win + j * w1 + 8);
+            const u64 p01 = pack64(wa.x, wa.y), p12 = pack64(wa.y, wb.x), p23 = pack64(wb.x, wb.y);
+#pragma unroll
+            for (int dd = 0; dd < 3; dd++) {
+                const int r = j - dd;
+                if (r < 0 || r >= 8) continue;
+                lo[dd] = qsad(p01, tile[r][0], lo[dd]);
+                lo[dd] = qsad(p12, tile[r][1], lo[dd]);
+                hi[dd] = qsad(p12, tile[r][0], hi[dd]);
+                hi[dd] = qsad(p23, tile[r][1], hi[dd]);
+                a8[dd] = __builtin_amdgcn_sad_hi_u8(wb.x, tile[r][0], a8[dd]);
+                a8[dd] = __builtin_amdgcn_sad_hi_u8(wb.y, tile[r][1], a8[dd]);
+            }
+        }
+        uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int dd = 0; dd < 3; dd++) {
+            const uint32_t base = (uint32_t)((d0 + dd) * 9);
+            const uint32_t l0 = (uint32_t)lo[dd], l1w = (uint32_t)(lo[dd] >> 32), h0 = (uint32_t)hi[dd], h1w = (uint32_t)(hi[dd] >> 32);
+            const uint32_t k0 = (l0 << 16) | (base + 0), k1 = (l0 & 0xFFFF0000u) | (base + 1);
+            const uint32_t k2 = (l1w << 16) | (base + 2), k3 = (l1w & 0xFFFF0000u) | (base + 3);
+            const uint32_t k4 = (h0 << 16) | (base + 4), k5 = (h0 & 0xFFFF0000u) | (base + 5);
+            const uint32_t k6 = (h1w << 16) | (base + 6), k7 = (h1w & 0xFFFF0000u) | (base + 7);
+            best = min(best, min(min(k0, k1), k2));
+            best = min(best, min(min(k3, k4), k5));
+            best = min(best, min(min(k6, k7), a8[dd]));
+        }
         atomicMin(&keys[blk], best);
     }
     lds_barrier();
