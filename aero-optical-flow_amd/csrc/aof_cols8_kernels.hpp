@@ -199,8 +199,8 @@ __device__ __forceinline__ void cols_walk(const SearchArgs &a, const ColsPlan &p
                     const bool have_ring = dyi == udy && udy >= 1 && udy <= 7 && dxi >= 1 && dxi <= 7;
                     RefineState<2> st;
                     st.init();
-                    if (have_ring) refine_from_window(win, udy, dxi - 1, ref, st);
-                    if (!have_ring) {
+                    if (have_ring) refine_from_window(win, udy, dxi - 1, ref, st, (uint32_t)rec.sad);
+                    if (!have_ring && rec.sad != 0) {   // (nothing is below a SAD of zero)
                         const uint32_t ring = off_cur8 + (uint32_t)((dyi - 9) * W + (dxi - 1));   // (the match's row - 1: >= 0)
                         uint32_t rows[10][3];
                         load_ring(rs_cur, ring, W, records, rows);

@@ -285,30 +285,38 @@ __device__ __forceinline__ int vote_start_row(const uint4 (&win)[16], const uint
 // Half-pixel refinement with the ring taken out of the 16x16 window in registers: rows udy-1 .. udy+8 (udy wave-uniform,
 // 1..7: compile-time inside the switch), bytes o .. o+9 (o per lane, 0..6: a v_alignbyte per dword).  Row by row, so
 // that nothing but the window and the refinement's own state is live (the kernel stays at four waves per SIMD).
+// `sad`: the integer match's SAD of the lane; the walk over the ring rows ends as soon as no lane in this control flow can
+// still find a direction below it (RefineState::nobody_can_win).
 template <int UDY>
-__device__ __forceinline__ void refine_rows_from_window(const uint4 (&win)[16], int o, const uint32_t (&ref)[8][2], RefineState<2> &st)
+__device__ __forceinline__ void refine_rows_from_window(const uint4 (&win)[16], int o, const uint32_t (&ref)[8][2], RefineState<2> &st,
+                                                        uint32_t sad)
 {
     const bool upper = o >= 4;   // (v_alignbyte shifts by o & 3)
+    bool over = false;           // (wave-uniform)
     for_rows<-1, 8>([&](auto yc) {
         constexpr int Y = decltype(yc)::value;
+        if (over) return;
         const uint4 w = win[UDY + Y];
         const uint32_t a0 = __builtin_amdgcn_alignbyte(w.y, w.x, (uint32_t)o), a1 = __builtin_amdgcn_alignbyte(w.z, w.y, (uint32_t)o);
         const uint32_t a2 = __builtin_amdgcn_alignbyte(w.w, w.z, (uint32_t)o), a3 = __builtin_amdgcn_alignbyte(0u, w.w, (uint32_t)o);
         const uint32_t d[3] = {upper ? a1 : a0, upper ? a2 : a1, (upper ? a3 : a2) & 0xFFFFu};
         st.template row<Y>(d, ref);
+        if constexpr (Y == 1 || Y == 3 || Y == 5) over = st.nobody_can_win(sad);   // (every direction has a tile row from Y = 1 on)
     });
 }
 
-__device__ __forceinline__ void refine_from_window(const uint4 (&win)[16], int udy, int o, const uint32_t (&ref)[8][2], RefineState<2> &st)
+__device__ __forceinline__ void refine_from_window(const uint4 (&win)[16], int udy, int o, const uint32_t (&ref)[8][2], RefineState<2> &st,
+                                                   uint32_t sad)
 {
+    if (__ballot(sad != 0) == 0) return;   // (matches without a single count of difference: nothing can be below them)
     switch (udy) {
-    case 1: refine_rows_from_window<1>(win, o, ref, st); break;
-    case 2: refine_rows_from_window<2>(win, o, ref, st); break;
-    case 3: refine_rows_from_window<3>(win, o, ref, st); break;
-    case 4: refine_rows_from_window<4>(win, o, ref, st); break;
-    case 5: refine_rows_from_window<5>(win, o, ref, st); break;
-    case 6: refine_rows_from_window<6>(win, o, ref, st); break;
-    default: refine_rows_from_window<7>(win, o, ref, st); break;
+    case 1: refine_rows_from_window<1>(win, o, ref, st, sad); break;
+    case 2: refine_rows_from_window<2>(win, o, ref, st, sad); break;
+    case 3: refine_rows_from_window<3>(win, o, ref, st, sad); break;
+    case 4: refine_rows_from_window<4>(win, o, ref, st, sad); break;
+    case 5: refine_rows_from_window<5>(win, o, ref, st, sad); break;
+    case 6: refine_rows_from_window<6>(win, o, ref, st, sad); break;
+    default: refine_rows_from_window<7>(win, o, ref, st, sad); break;
     }
 }
 
@@ -534,8 +542,8 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
                 const bool have_ring = dyi == udy && udy >= 1 && udy <= 7 && dxi >= 1 && dxi <= 7;
                 RefineState<2> st;
                 st.init();
-                if (have_ring) refine_from_window(win, udy, dxi - 1, ref, st);
-                if (!have_ring) {
+                if (have_ring) refine_from_window(win, udy, dxi - 1, ref, st, (uint32_t)rec.sad);
+                if (!have_ring && rec.sad != 0) {   // (nothing is below a SAD of zero)
                     load_ring(rs_cur, ring, W, records, rows);
                     for_rows<-1, 8>([&](auto yc) {
                         constexpr int Y = decltype(yc)::value;
@@ -548,18 +556,21 @@ __device__ __forceinline__ int search_block(const SearchArgs &a, uint32_t pair, 
                     });
                 }
                 subdir = st.direction(rec.sad);
-            } else {
+            } else if (rec.sad != 0) {   // (nothing is below a SAD of zero: no ring is loaded for such a match)
             load_ring(rs_cur, ring, W, records, rows);
             RefineState<2> st;
             st.init();
+            bool over = false;   // (uniform among the lanes in here: RefineState::nobody_can_win)
             for_rows<-1, 8>([&](auto yc) {
                 constexpr int Y = decltype(yc)::value;
+                if (over) return;
                 uint32_t d[3] = {rows[Y + 1][0], rows[Y + 1][1], rows[Y + 1][2]};
                 if (delta != 0) {
 #pragma unroll
                     for (int q = 0; q < 3; q++) d[q] = sat_add_u8x4(d[q], delta);
                 }
                 st.template row<Y>(d, ref);
+                if constexpr (Y == 1 || Y == 3 || Y == 5) over = st.nobody_can_win((uint32_t)rec.sad);
             });
             subdir = st.direction(rec.sad);
             }

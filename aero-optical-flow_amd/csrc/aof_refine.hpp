@@ -73,6 +73,15 @@ struct RefineState {
         for (int q = 0; q < NW; q++) { pc[q] = c[q]; ph[q] = hp[q]; pl[q] = hm[q]; }
     }
 
+    // The direction sums only grow, and a direction wins only with a sum BELOW the integer match's SAD: once no lane of the
+    // wave that is still refining has such a sum, every one of them ends with "none" and the rows that are left change nothing.
+    // (Exact; what it saves depends on the input: integer shifts stop after two of ten ring rows, a true half-pixel motion never.)
+    __device__ __forceinline__ bool nobody_can_win(uint32_t integer_sad) const
+    {
+        const uint32_t m = min(min(min(acc[0], acc[1]), min(acc[2], acc[3])), min(min(acc[4], acc[5]), min(acc[6], acc[7])));
+        return __ballot(m < integer_sad) == 0;   // (the lanes in this control flow)
+    }
+
     // first direction whose SAD beats the integer match, 8 = none
     __device__ __forceinline__ int direction(uint32_t integer_sad) const
     {

@@ -146,7 +146,7 @@ __device__ __forceinline__ void run_level(const SearchArgs &a, const FlowTail &t
             const bool refine = key != 0xFFFFFFFFu && (key >> 16) < (uint32_t)a.value_threshold;
             RefineState<2, kRows> st;
             st.init();
-            if (refine) {
+            if (refine && (key >> 16) != 0) {   // (nothing is below a SAD of zero: such a match keeps "none" from the empty sums)
                 const int idx = (int)(key & 0xFFFFu);
                 const int by = blk / nx, bx = blk - by * nx;
                 const int i = a.grid.x0 + bx * a.grid.step_x, j = a.grid.y0 + by * a.grid.step_y + kRows * part;

@@ -434,7 +434,10 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
             const bool live = key != 0xFFFFFFFFu;
             RefineState<4, kRows> st;
             st.init();
-            if (live) {
+            // (a match without a single count of difference has nothing below it; and a slice's direction sums are lower
+            //  bounds of the block's: once no lane of the wave has one below its block's SAD, the rows that are left change nothing)
+            if (live && (key >> 16) != 0) {
+                bool over = false;   // (uniform among the lanes in here)
                 const int idx = (int)(key & 0xFFFFu), dxi = idx % kSide, dyi = idx / kSide;
                 uint32_t ref[kRows][4];
 #pragma unroll
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
                 const int off0 = (dyi + kRows * part - 1) * W + (16 * bx + px - sh) + dxi - 1;
                 for_rows<-1, kRows>([&](auto yc) {
                     constexpr int Y = decltype(yc)::value;
+                    if (over) return;
                     const int off = off0 + (Y + 1) * W;
                     const uint32_t *w = reinterpret_cast<const uint32_t *>(s_cur + (off & ~3));   // (off >= -W - 1: inside the pad)
                     const uint32_t shb = (uint32_t)off & 3u;
@@ -454,6 +458,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
                                            __builtin_amdgcn_alignbyte(q3, q2, shb), __builtin_amdgcn_alignbyte(q4, q3, shb),
                                            __builtin_amdgcn_alignbyte(q5, q4, shb)};
                     st.template row<Y>(d, ref);
+                    if constexpr (Y == 1) over = st.nobody_can_win(key >> 16);
                 });
             }
 #pragma unroll
