@@ -153,10 +153,19 @@ __device__ __forceinline__ uint32_t exhaustive_search_judged(const uint4 (&win)[
 // translation), so the test is kept short: ONE accumulator set (64 pixels x 255 fit a u16 field),
 // the minimum over the nine offsets as four packed minima and one min, the ballot and its mask in
 // scalar registers -- about 9 instructions behind the row's first 12 SAD instructions.
-template <int D>
+// `zero` (wave-uniform, set behind the block's FIRST row): every needing lane's best match has SAD 0.  Nothing is below that,
+// and a row whose index lies BEHIND a lane's match cannot take a tie from it either (the key carries the index): best < 9 D as
+// a key says both, and such a row goes without a SAD instruction.  (On BASELINE's noise-free translations: every row behind
+// the matched one.  Where the matches have differences at all the flag is false and costs a scalar branch per row.)
+template <int D, bool FIRST = false>
 __device__ __forceinline__ bool pruned_row(const uint4 (&win)[16], const uint32_t (&ref)[8][2], unsigned long long needing,
-                                           uint32_t &best)
+                                           uint32_t &best, bool &zero)
 {
+    if constexpr (D > 0 && !FIRST) {
+        if (zero) {
+            if ((__ballot(best >= (uint32_t)(9 * D)) & needing) == 0) return false;
+        }
+    }
     u64 alo = 0, ahi = 0;
     uint32_t a8 = (uint32_t)(D * 9 + 8);
     auto row_pair = [&](int r) {
@@ -194,6 +203,7 @@ __device__ __forceinline__ bool pruned_row(const uint4 (&win)[16], const uint32_
     best = min(best, min(min(k0, k1), k2));
     best = min(best, min(min(k3, k4), k5));
     best = min(best, min(min(k6, k7), a8));
+    if constexpr (FIRST) zero = (__ballot((best >> 16) != 0) & needing) == 0;
     return true;
 }
 
@@ -212,10 +222,10 @@ constexpr int visit_order(int start, int k)
 // register (a run-time row index would push the 64-register window into scratch).
 template <int START, int K = 0>
 __device__ __forceinline__ int pruned_from(const uint4 (&win)[16], const uint32_t (&ref)[8][2], unsigned long long need,
-                                           uint32_t &best)
+                                           uint32_t &best, bool &zero)
 {
-    const int dropped = pruned_row<visit_order(START, K)>(win, ref, need, best) ? 0 : 1;
-    if constexpr (K < 8) return dropped + pruned_from<START, K + 1>(win, ref, need, best);
+    const int dropped = pruned_row<visit_order(START, K), K == 0>(win, ref, need, best, zero) ? 0 : 1;
+    if constexpr (K < 8) return dropped + pruned_from<START, K + 1>(win, ref, need, best, zero);
     else return dropped;
 }
 
@@ -224,16 +234,17 @@ __device__ __forceinline__ int pruned_from(const uint4 (&win)[16], const uint32_
 __device__ __forceinline__ int pruned_search(const uint4 (&win)[16], const uint32_t (&ref)[8][2], unsigned long long need,
                                              int start, uint32_t &best)
 {
+    bool zero = false;
     switch (start) {
-    case 0: return pruned_from<0>(win, ref, need, best);
-    case 1: return pruned_from<1>(win, ref, need, best);
-    case 2: return pruned_from<2>(win, ref, need, best);
-    case 3: return pruned_from<3>(win, ref, need, best);
-    case 4: return pruned_from<4>(win, ref, need, best);
-    case 5: return pruned_from<5>(win, ref, need, best);
-    case 6: return pruned_from<6>(win, ref, need, best);
-    case 7: return pruned_from<7>(win, ref, need, best);
-    default: return pruned_from<8>(win, ref, need, best);
+    case 0: return pruned_from<0>(win, ref, need, best, zero);
+    case 1: return pruned_from<1>(win, ref, need, best, zero);
+    case 2: return pruned_from<2>(win, ref, need, best, zero);
+    case 3: return pruned_from<3>(win, ref, need, best, zero);
+    case 4: return pruned_from<4>(win, ref, need, best, zero);
+    case 5: return pruned_from<5>(win, ref, need, best, zero);
+    case 6: return pruned_from<6>(win, ref, need, best, zero);
+    case 7: return pruned_from<7>(win, ref, need, best, zero);
+    default: return pruned_from<8>(win, ref, need, best, zero);
     }
 }
 
