@@ -663,3 +663,33 @@ def test_column_walk_under_every_window_alignment(aof, orc, synth, gpu_device, k
     prevs.append(a); curs.append(b)
     check = half_pixel_modes_match_oracle if p.subpixel else both_modes_match_oracle
     check(aof, orc, p, np.stack(prevs), np.stack(curs), gpu_device)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(subpixel=1), dict(pyramid_levels=2, mean_subtract=1)])
+def test_perfect_matches_in_different_rows_of_one_wave(aof, orc, synth, gpu_device, kw):
+    """Noise-free frames cut from patches that moved differently: the lanes of a wave find SAD 0 in different dy rows,
+    some patches carry a period-2 texture (SAD 0 in several rows: the tie goes to the first in scan order), one is
+    displaced by half a pixel and one is noise -- the rows behind a perfect match that go unsummed (aof_lane8.hpp,
+    pruned_row's `zero`) and the refinement that ends early (aof_refine.hpp, nobody_can_win) must not change a byte."""
+    w, h, reach = 640, 160, 9 if kw.get("pyramid_levels") == 2 else 4
+    p = aof.default_params(w, h, **kw)
+    rng = np.random.default_rng(77)
+    prevs, curs = [], []
+    for k in range(3):
+        prev = np.zeros((h, w), np.uint8)
+        cur = np.zeros((h, w), np.uint8)
+        for i, x0 in enumerate(range(0, w, 80)):   # eight vertical stripes of ten block columns: several per wave
+            s = int(reach)
+            shift = [(0, -s), (s, s), (-1, 2), (3, -3), (-s, 0), (2, 1), (0, 0), (1, -s + 1)][(i + k) % 8]
+            half = (1, 0) if (i + k) % 8 == 5 and kw.get("subpixel") else (0, 0)
+            a, b, _ = synth.make_pair(80, h, reach, 500 + 8 * k + i, shift=shift, half=half)
+            if (i + k) % 8 == 3:                   # period 2 in x and y: ties between rows and columns
+                a = np.zeros((h, 80), np.uint8)
+                a[0::2, 0::2] = 220
+                b = a.copy()
+            if (i + k) % 8 == 6:                   # unrelated noise: no perfect match in these lanes
+                b = rng.integers(0, 256, b.shape, dtype=np.uint8)
+            prev[:, x0:x0 + 80], cur[:, x0:x0 + 80] = a, b
+        prevs.append(prev)
+        curs.append(cur)
+    both_modes_match_oracle(aof, orc, p, np.stack(prevs), np.stack(curs), gpu_device)
