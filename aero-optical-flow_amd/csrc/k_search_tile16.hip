@@ -37,6 +37,12 @@ __host__ __device__ constexpr int probe_samples(int n, int stride) { return (n +
 //  6 x / 35 % the mode follows the faster of the two fixed modes within 5 % at every noise level but one, 8 %)
 constexpr uint32_t kFullOverBound = 6;     // a row can survive when its two-row bound <= this x the block's smallest bound
 constexpr uint32_t kMaxSurvivorsPct = 35;  // more predicted survivors than this: the exhaustive scan is faster
+// ONE-row bounds in step A (half its SAD instructions) where the probe finds that one tile row separates the candidates already
+// -- noise-free pairs: c5 310 -> 260 us per 256 pairs; from +-2 LSB on the two-row bounds are the cheaper way (1-row bounds for
+// every pair: +-2 LSB 326 -> 391 us) --: hints[pair] = 2.  A row would survive its one-row bound when that does not exceed
+// kFullOverOneRow times the block's smallest one; at most kMaxOneRowSurvivorsPct of them may.
+constexpr uint32_t kFullOverOneRow = 12;
+constexpr uint32_t kMaxOneRowSurvivorsPct = 4;
 constexpr int kRefineParts = 4;  // lanes per block in the half-pixel refinement (1: 3.56, 2: 3.31, 4: 3.28 ms per 1 024 c5h pairs)
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
@@ -199,7 +205,8 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * a.h));
     // ADAPTIVE (a.prune == 2): the probe kernel in front of this launch has judged the pair (a.hints); PRUNED: always
     typedef const __attribute__((address_space(4))) uint32_t *const_u32;   // (scalar load: uniform in the workgroup)
-    const bool pays = PRUNE && (a.prune != 2 || ((const_u32)a.hints)[pair] != 0u);
+    const uint32_t hint = PRUNE ? (a.prune != 2 ? 1u : ((const_u32)a.hints)[pair]) : 0u;   // 0: exhaustive scan, 1: two-row bounds, 2: one-row bounds
+    const bool pays = hint != 0u, one_row = hint == 2u;
 
     // Level 0 under a predictor (px, py): the block row's windows move by py rows and px columns.
     // The cur rows are staged PRE-SHIFTED by px mod 16, so that LDS column c
@@ -303,7 +310,9 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
             const int dyi = (int)fast_div((uint32_t)item, a.div_nx), bx = item - dyi * nx;
             const int xf = 16 * bx + px;
             uint32_t bound = 0xFFFFu;
-            if (!(xf < 0 || xf + 32 > Wb)) bound = bound_item<kBoundRows, 16 / kBoundRows>(s_prev, s_cur, W, dyi, bx, xf - sh, 8 / kBoundRows);
+            if (!(xf < 0 || xf + 32 > Wb))   // (uniform in the workgroup: the pair's hint)
+                bound = one_row ? bound_item<1, 16>(s_prev, s_cur, W, dyi, bx, xf - sh, 8 / kBoundRows)
+                                : bound_item<kBoundRows, 16 / kBoundRows>(s_prev, s_cur, W, dyi, bx, xf - sh, 8 / kBoundRows);
             s_pmin[item] = (uint16_t)bound;
         }
         __syncthreads();
@@ -481,8 +490,8 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
 // only: both branches of the search kernel write the same records.
 __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, uint32_t *hints, int stride_x, int stride_y)
 {
-    __shared__ uint16_t s_bound[kProbeMaxBlocks][kSide + 1];
-    __shared__ uint32_t s_tot[2];
+    __shared__ uint16_t s_bound[kProbeMaxBlocks][kSide + 1], s_bound1[kProbeMaxBlocks][kSide + 1];   // two-row, one-row bounds
+    __shared__ uint32_t s_tot[3];
     const int64_t pair = blockIdx.x;
     const int tid = threadIdx.x, W = a.w, nx = a.grid.nx, ny = a.grid.ny;
     const int sx = probe_samples(nx, stride_x), sy = probe_samples(ny, stride_y);   // blocks stride/2, + stride, ... per axis
@@ -494,35 +503,47 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
     const int H = a.h - 2 * org, Wb = W - 2 * org;
     const uint8_t *prev = a.prev + pair * a.pair_stride + (int64_t)org * (W + 1);
     const uint8_t *cur = a.cur + pair * a.pair_stride + (int64_t)org * (W + 1);
-    if (tid < 2) s_tot[tid] = 0;
+    if (tid < 3) s_tot[tid] = 0;
     for (int s = tid; s < kSide * nsamp; s += kProbeThreads) {
         const int blk = s / kSide, dyi = s - blk * kSide;
         const int by = (blk / sx) * stride_y + stride_y / 2, bx = (blk % sx) * stride_x + stride_x / 2;
         const int xf = 16 * bx + px, yc0 = 16 * by + py;
-        uint32_t bound = 0xFFFFu;
-        if (xf >= 0 && xf + 32 <= Wb && yc0 >= 0 && yc0 + 32 <= H)
+        uint32_t bound = 0xFFFFu, bound1 = 0xFFFFu;
+        if (xf >= 0 && xf + 32 <= Wb && yc0 >= 0 && yc0 + 32 <= H) {
             bound = bound_item<kBoundRows, 16 / kBoundRows>(prev + (int64_t)(16 * by + 8) * W + 8, cur + (int64_t)yc0 * W, W, dyi, bx, xf,
                                                             8 / kBoundRows, delta);
+            bound1 = bound_item<1, 16>(prev + (int64_t)(16 * by + 8) * W + 8, cur + (int64_t)yc0 * W, W, dyi, bx, xf, 8 / kBoundRows, delta);
+        }
         s_bound[blk][dyi] = (uint16_t)bound;
+        s_bound1[blk][dyi] = (uint16_t)bound1;
     }
     __syncthreads();
-    uint32_t would_survive = 0, rows = 0;
+    uint32_t would_survive = 0, would_survive1 = 0, rows = 0;
     for (int blk = tid; blk < nsamp; blk += kProbeThreads) {
-        uint32_t m = 0xFFFFu;
+        uint32_t m = 0xFFFFu, m1 = 0xFFFFu;
 #pragma unroll
-        for (int d = 0; d < kSide; d++) m = min(m, (uint32_t)s_bound[blk][d]);
+        for (int d = 0; d < kSide; d++) { m = min(m, (uint32_t)s_bound[blk][d]); m1 = min(m1, (uint32_t)s_bound1[blk][d]); }
         if (m == 0xFFFFu) continue;   // window outside the frame: the block is skipped anyway
-        const uint32_t limit = kFullOverBound * m;
+        const uint32_t limit = kFullOverBound * m, limit1 = kFullOverOneRow * m1;
 #pragma unroll
-        for (int d = 0; d < kSide; d++) would_survive += (uint32_t)s_bound[blk][d] <= limit ? 1u : 0u;
+        for (int d = 0; d < kSide; d++) {
+            would_survive += (uint32_t)s_bound[blk][d] <= limit ? 1u : 0u;
+            would_survive1 += (uint32_t)s_bound1[blk][d] <= limit1 ? 1u : 0u;
+        }
         would_survive -= 1;            // (the best row itself is evaluated completely either way)
+        would_survive1 -= 1;
         rows += kSide - 1;
     }
     would_survive = wave_sum_u32(would_survive);
+    would_survive1 = wave_sum_u32(would_survive1);
     rows = wave_sum_u32(rows);
-    if ((tid & 63) == 0) { atomicAdd(&s_tot[0], would_survive); atomicAdd(&s_tot[1], rows); }
+    if ((tid & 63) == 0) { atomicAdd(&s_tot[0], would_survive); atomicAdd(&s_tot[1], rows); atomicAdd(&s_tot[2], would_survive1); }
     __syncthreads();
-    if (tid == 0) hints[pair] = (s_tot[1] != 0 && 100u * s_tot[0] > kMaxSurvivorsPct * s_tot[1]) ? 0u : 1u;
+    if (tid == 0) {
+        uint32_t hint = (s_tot[1] != 0 && 100u * s_tot[0] > kMaxSurvivorsPct * s_tot[1]) ? 0u : 1u;
+        if (hint == 1u && s_tot[1] != 0 && 100u * s_tot[2] <= kMaxOneRowSurvivorsPct * s_tot[1]) hint = 2u;
+        hints[pair] = hint;
+    }
 }
 
 size_t tile16_lds(const SearchArgs &a)

@@ -317,9 +317,10 @@ def test_pruned16_fuzz(aof, orc, synth, gpu_device, seed):
 
 def test_adaptive16_is_the_default_and_judges_every_pair_by_itself(aof, orc, synth, gpu_device):
     """A fresh 16x16 context runs AOF_SEARCH_ADAPTIVE: a probe kernel in front of the search judges every pair
-    (aof_ws_layout.hints: 1 = few candidates survive the two-row bounds, run the pruned steps; 0 = noise, run
-    the exhaustive scan) and the search follows the verdict per pair.  A batch that mixes clean translations,
-    heavy sensor noise, unrelated frames and a flat pair must come out with BOTH verdicts present, records and
+    (aof_ws_layout.hints: 2 = one tile row separates the candidates already, 1 = few candidates survive the two-row
+    bounds: run the pruned steps on one- or two-row bounds; 0 = noise, run the exhaustive scan) and the search follows
+    the verdict per pair.  A batch that mixes noise-free translations, a little and a lot of sensor noise, unrelated
+    frames and a flat pair must come out with ALL verdicts present, records and
     flows equal to the oracle's for every pair, and the same bytes as the two fixed modes -- for one and two
     levels and with the half-pixel step."""
     import torch
@@ -329,25 +330,27 @@ def test_adaptive16_is_the_default_and_judges_every_pair_by_itself(aof, orc, syn
         reach = 17 if kw.get("pyramid_levels") == 2 else 8
         clean_p, clean_c, _ = synth.make_batch(W, H, 2, reach, 7100, brightness=9 if kw.get("mean_subtract") else 0)
         noisy_p, noisy_c, _ = synth.make_batch(W, H, 2, reach, 7200, noise=40)
+        some_p, some_c, _ = synth.make_batch(W, H, 1, reach, 7300, noise=3, brightness=9 if kw.get("mean_subtract") else 0)
         rng = np.random.default_rng(72)
         unrelated = rng.integers(0, 256, (H, W), dtype=np.uint8)
         flat = np.full((H, W), 90, np.uint8)
-        prevs = np.stack([clean_p[0], noisy_p[0], clean_p[1], noisy_p[1], clean_p[0], flat])
-        curs = np.stack([clean_c[0], noisy_c[0], clean_c[1], noisy_c[1], unrelated, flat])
+        prevs = np.stack([clean_p[0], noisy_p[0], clean_p[1], noisy_p[1], clean_p[0], flat, some_p[0]])
+        curs = np.stack([clean_c[0], noisy_c[0], clean_c[1], noisy_c[1], unrelated, flat, some_c[0]])
         eng = aof.FlowEngine(p, 0)
         assert eng.search_mode == aof.SEARCH_ADAPTIVE and eng.variant == "tile16_lds"
         tp, tc = torch.from_numpy(prevs).to(gpu_device), torch.from_numpy(curs).to(gpu_device)
-        L = aof.workspace_layout(p, 6)
+        L = aof.workspace_layout(p, 7)
         ws = torch.full((L.total_bytes,), 0x5A, dtype=torch.uint8, device=gpu_device)
         blocks, flows, _ = eng.flow_batch(tp, tc, workspace=ws)
         torch.cuda.synchronize()
-        hints = ws[L.hints:L.hints + 4 * 6].cpu().numpy().view(np.uint32)
-        assert set(hints.tolist()) <= {0, 1}
-        assert hints[0] == 1 and hints[2] == 1, hints          # clean translations: pruning pays
+        hints = ws[L.hints:L.hints + 4 * 7].cpu().numpy().view(np.uint32)
+        assert set(hints.tolist()) <= {0, 1, 2}
+        assert hints[0] == 2 and hints[2] == 2, hints          # noise-free translations: pruning pays, on one-row bounds
+        assert hints[6] == 1, hints                            # +-3 LSB: pruning pays, on the two-row bounds
         assert hints[1] == 0 and hints[3] == 0 and hints[4] == 0, hints   # noise / unrelated frames: it does not
         got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
         po = orc.params_from(p)
-        for i in range(6):
+        for i in range(7):
             ref = orc.flow_pair(po, prevs[i], curs[i])
             assert got["blocks"][i].tobytes() == ref["blocks"].tobytes(), (kw, i)
             assert got["flows"][i].tobytes() == ref["flow"].tobytes(), (kw, i)
