@@ -145,8 +145,8 @@ int aof_set_force_generic(aof_ctx *ctx, int on);
  *   and prune the next blocks where they could -- reports the share of blocks that pruned (plain stores into pinned
  *   host memory, read at the next enqueue, never waited for).  While that share is at least 40 % the context keeps
  *   launching it, and its waves prune from their FIRST block on (which votes for the dy row to start in; round 5) --
- *   1 024 VGA pairs per launch, same box (profiles/r05_final_c2_noise.txt): noise-free translations 1.85x EXHAUSTIVE, +-2 LSB
- *   of noise 1.63x, +-4 LSB 1.54x, +-8 LSB 1.23x --; otherwise it launches the exhaustive kernel, and the pruned one once in 16
+ *   1 024 VGA pairs per launch, same box (profiles/r05_final_c2_noise.txt): noise-free translations 1.6-1.85x EXHAUSTIVE, +-2 LSB
+ *   of noise 1.5x, +-4 LSB 1.4x, +-8 LSB 1.2x --; otherwise it launches the exhaustive kernel, and the pruned one once in 16
  *   launches to look again (+-16 LSB and more: within 1 % of EXHAUSTIVE, where PRUNED alone loses 12 %).  A context's
  *   first launch and a graph captured from it use whatever is known at that moment (aof_set_search_belief tells a fresh
  *   context); half-pixel configurations prune too.  aof_get_search_stats tells what happened. */
