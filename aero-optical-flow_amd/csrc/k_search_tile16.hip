@@ -43,6 +43,13 @@ constexpr uint32_t kMaxSurvivorsPct = 35;  // more predicted survivors than this
 // kFullOverOneRow times the block's smallest one; at most kMaxOneRowSurvivorsPct of them may.
 constexpr uint32_t kFullOverOneRow = 12;
 constexpr uint32_t kMaxOneRowSurvivorsPct = 4;
+// DEEPER bounds where two rows do not separate the candidates any more (sensor noise): a partial sum over four or eight of
+// the sixteen tile rows is a lower bound like any other, costs a quarter or half of the exhaustive scan in step A, and still
+// drops most rows where the two-row bound drops none -- hints[pair] = 3 (four rows) or 4 (eight rows).  The probe sums them only
+// for pairs it would otherwise send to the exhaustive scan, and it does not guess there: it evaluates the sample blocks' best
+// row completely (what step B1 will do) and counts the rows whose deeper bound does not exceed THAT -- the survivors the search
+// will really have.  A verdict needs the expected work -- step A + the survivors' sums -- well under the exhaustive scan's.
+constexpr uint32_t kMaxFourRowSurvivorsPct = 40, kMaxEightRowSurvivorsPct = 10;
 constexpr int kRefineParts = 4;  // lanes per block in the half-pixel refinement (1: 3.56, 2: 3.31, 4: 3.28 ms per 1 024 c5h pairs)
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
@@ -205,8 +212,8 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * a.h));
     // ADAPTIVE (a.prune == 2): the probe kernel in front of this launch has judged the pair (a.hints); PRUNED: always
     typedef const __attribute__((address_space(4))) uint32_t *const_u32;   // (scalar load: uniform in the workgroup)
-    const uint32_t hint = PRUNE ? (a.prune != 2 ? 1u : ((const_u32)a.hints)[pair]) : 0u;   // 0: exhaustive scan, 1: two-row bounds, 2: one-row bounds
-    const bool pays = hint != 0u, one_row = hint == 2u;
+    const uint32_t hint = PRUNE ? (a.prune != 2 ? 1u : ((const_u32)a.hints)[pair]) : 0u;   // 0: exhaustive scan; 1, 2, 3, 4: step A on two-, one-, four-, eight-row bounds
+    const bool pays = hint != 0u;
 
     // Level 0 under a predictor (px, py): the block row's windows move by py rows and px columns.
     // The cur rows are staged PRE-SHIFTED by px mod 16, so that LDS column c
@@ -306,6 +313,18 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
         }
         const int items_all = items;
         const int items = pays ? items_all : 0;   // (the pruned steps below then have nothing to do)
+        if (hint >= 3u) {   // (sensor noise: deeper bounds; the pair's verdict is uniform in the workgroup)
+            for (int item = tid; item < items; item += kThreads) {
+                const int dyi = (int)fast_div((uint32_t)item, a.div_nx), bx = item - dyi * nx;
+                const int xf = 16 * bx + px;
+                uint32_t bound = 0xFFFFu;
+                if (!(xf < 0 || xf + 32 > Wb))
+                    bound = hint == 3u ? bound_item<4, 4>(s_prev, s_cur, W, dyi, bx, xf - sh, 2)    // rows 2, 6, 10, 14
+                                       : bound_item<8, 2>(s_prev, s_cur, W, dyi, bx, xf - sh, 0);   // rows 0, 2, .., 14
+                s_pmin[item] = (uint16_t)bound;
+            }
+        } else {
+        const bool one_row = hint == 2u;
         for (int item = tid; item < items; item += kThreads) {
             const int dyi = (int)fast_div((uint32_t)item, a.div_nx), bx = item - dyi * nx;
             const int xf = 16 * bx + px;
@@ -314,6 +333,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
                 bound = one_row ? bound_item<1, 16>(s_prev, s_cur, W, dyi, bx, xf - sh, 8 / kBoundRows)
                                 : bound_item<kBoundRows, 16 / kBoundRows>(s_prev, s_cur, W, dyi, bx, xf - sh, 8 / kBoundRows);
             s_pmin[item] = (uint16_t)bound;
+        }
         }
         __syncthreads();
         // (four lanes per block, four interleaved tile rows each, sums joined across the quad: the
@@ -539,11 +559,90 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
     rows = wave_sum_u32(rows);
     if ((tid & 63) == 0) { atomicAdd(&s_tot[0], would_survive); atomicAdd(&s_tot[1], rows); atomicAdd(&s_tot[2], would_survive1); }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t hint = (s_tot[1] != 0 && 100u * s_tot[0] > kMaxSurvivorsPct * s_tot[1]) ? 0u : 1u;
-        if (hint == 1u && s_tot[1] != 0 && 100u * s_tot[2] <= kMaxOneRowSurvivorsPct * s_tot[1]) hint = 2u;
-        hints[pair] = hint;
+    uint32_t hint = (s_tot[1] != 0 && 100u * s_tot[0] > kMaxSurvivorsPct * s_tot[1]) ? 0u : 1u;   // (uniform: LDS totals)
+    if (hint == 1u && s_tot[1] != 0 && 100u * s_tot[2] <= kMaxOneRowSurvivorsPct * s_tot[1]) hint = 2u;
+    // two rows do not separate the candidates: do four, do eight?  (Only these pairs pay for the deeper sums -- their search
+    // takes twice as long as a clean pair's anyway.)
+    if (hint == 0u && s_tot[1] != 0) {   // (uniform)
+        __shared__ uint16_t s_full[kProbeMaxBlocks];   // the sample blocks' best SAD after step B1: the row with the smallest two-row bound, complete
+        __syncthreads();
+        if (tid < 3) s_tot[tid] = 0;
+        // (the probe is bound by its scattered loads: the deeper look takes every OTHER sample block)
+        // (a) what step B1 will find: four lanes per block, four interleaved tile rows each, joined across the quad
+        for (int q = tid; q < (4 * ((nsamp + 1) / 2) + 63) / 64 * 64; q += kProbeThreads) {   // whole waves: shuffles
+            const int blk = 2 * (q >> 2), part = q & 3;
+            uint32_t m = 0xFFFFFFFFu;
+            if (blk < nsamp) {
+#pragma unroll
+                for (int d = 0; d < kSide; d++) m = min(m, ((uint32_t)s_bound[blk][d] << 8) | (uint32_t)d);
+            }
+            const bool in = blk < nsamp && (m >> 8) != 0xFFFFu;
+            u64 acc[4] = {0, 0, 0, 0};
+            uint32_t acc16 = 0;
+            if (in) {
+                const int by = (blk / sx) * stride_y + stride_y / 2, bx = (blk % sx) * stride_x + stride_x / 2;
+                sum_item<4, 4>(prev + (int64_t)(16 * by + 8) * W + 8, cur + (int64_t)(16 * by + py) * W, W, (int)(m & 0xFFu), bx, 16 * bx + px, part, acc, acc16, delta);
+            }
+#pragma unroll
+            for (int o = 1; o <= 2; o <<= 1) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t lo = (uint32_t)acc[g] + (uint32_t)__shfl_xor((int)(uint32_t)acc[g], o, 64);
+                    const uint32_t hi = (uint32_t)(acc[g] >> 32) + (uint32_t)__shfl_xor((int)(uint32_t)(acc[g] >> 32), o, 64);
+                    acc[g] = pack64(lo, hi);
+                }
+                acc16 += (uint32_t)__shfl_xor((int)acc16, o, 64);
+            }
+            if (blk < nsamp && part == 0) s_full[blk] = in ? (uint16_t)(row_key(acc, acc16, 0) >> 16) : (uint16_t)0xFFFFu;
+        }
+        // (b) the four-row bounds (tile rows 2, 6, 10, 14) and the eight-row bounds (+ rows 0, 4, 8, 12) of those blocks' items in
+        //     one pass (24 loads per item)
+        const int ndeep = (nsamp + 1) / 2;
+        for (int s = tid; s < kSide * ndeep; s += kProbeThreads) {
+            const int blk = 2 * (s / kSide), dyi = s - (s / kSide) * kSide;
+            const int by = (blk / sx) * stride_y + stride_y / 2, bx = (blk % sx) * stride_x + stride_x / 2;
+            const int xf = 16 * bx + px, yc0 = 16 * by + py;
+            uint32_t b4 = 0xFFFFu, b8 = 0xFFFFu;
+            if (xf >= 0 && xf + 32 <= Wb && yc0 >= 0 && yc0 + 32 <= H) {
+                u64 acc[4] = {0, 0, 0, 0};
+                uint32_t acc16 = 0;
+                auto smallest = [](const u64 (&acc)[4], uint32_t acc16) -> uint32_t {
+                    const uint32_t m01 = pk_min_u16(pk_min_u16((uint32_t)acc[0], (uint32_t)(acc[0] >> 32)), pk_min_u16((uint32_t)acc[1], (uint32_t)(acc[1] >> 32)));
+                    const uint32_t m23 = pk_min_u16(pk_min_u16((uint32_t)acc[2], (uint32_t)(acc[2] >> 32)), pk_min_u16((uint32_t)acc[3], (uint32_t)(acc[3] >> 32)));
+                    const uint32_t m = pk_min_u16(pk_min_u16(m01, m23), acc16 | 0xFFFFu);
+                    return min(m & 0xFFFFu, m >> 16);
+                };
+                sum_item<4, 4>(prev + (int64_t)(16 * by + 8) * W + 8, cur + (int64_t)yc0 * W, W, dyi, bx, xf, 2, acc, acc16, delta);
+                b4 = smallest(acc, acc16);
+                // (the same sums go on: u16 lanes, eight rows of 16 pixels stay below 65 536)
+                sum_item<4, 4>(prev + (int64_t)(16 * by + 8) * W + 8, cur + (int64_t)yc0 * W, W, dyi, bx, xf, 0, acc, acc16, delta);
+                b8 = smallest(acc, acc16);
+            }
+            s_bound[blk][dyi] = (uint16_t)b4;
+            s_bound1[blk][dyi] = (uint16_t)b8;
+        }
+        __syncthreads();
+        uint32_t surv4 = 0, surv8 = 0, n = 0;
+        for (int blk = 2 * tid; blk < nsamp; blk += 2 * kProbeThreads) {
+            const uint32_t full = s_full[blk];
+            if (full == 0xFFFFu) continue;
+#pragma unroll
+            for (int d = 0; d < kSide; d++) {
+                surv4 += (uint32_t)s_bound[blk][d] <= full ? 1u : 0u;
+                surv8 += (uint32_t)s_bound1[blk][d] <= full ? 1u : 0u;
+            }
+            surv4 -= 1; surv8 -= 1;   // (the evaluated row itself)
+            n += kSide - 1;
+        }
+        surv4 = wave_sum_u32(surv4);
+        surv8 = wave_sum_u32(surv8);
+        n = wave_sum_u32(n);
+        if ((tid & 63) == 0) { atomicAdd(&s_tot[0], surv4); atomicAdd(&s_tot[1], n); atomicAdd(&s_tot[2], surv8); }
+        __syncthreads();
+        if (s_tot[1] != 0 && 100u * s_tot[0] <= kMaxFourRowSurvivorsPct * s_tot[1]) hint = 3u;
+        else if (s_tot[1] != 0 && 100u * s_tot[2] <= kMaxEightRowSurvivorsPct * s_tot[1]) hint = 4u;
     }
+    if (tid == 0) hints[pair] = hint;
 }
 
 size_t tile16_lds(const SearchArgs &a)

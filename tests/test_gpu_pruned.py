@@ -318,8 +318,8 @@ def test_pruned16_fuzz(aof, orc, synth, gpu_device, seed):
 def test_adaptive16_is_the_default_and_judges_every_pair_by_itself(aof, orc, synth, gpu_device):
     """A fresh 16x16 context runs AOF_SEARCH_ADAPTIVE: a probe kernel in front of the search judges every pair
     (aof_ws_layout.hints: 2 = one tile row separates the candidates already, 1 = few candidates survive the two-row
-    bounds: run the pruned steps on one- or two-row bounds; 0 = noise, run the exhaustive scan) and the search follows
-    the verdict per pair.  A batch that mixes noise-free translations, a little and a lot of sensor noise, unrelated
+    bounds, 3 / 4 = sensor noise that four / eight rows still see through: run the pruned steps on bounds of that depth;
+    0 = nothing separates the candidates, run the exhaustive scan) and the search follows the verdict per pair.  A batch that mixes noise-free translations, a little and a lot of sensor noise, unrelated
     frames and a flat pair must come out with ALL verdicts present, records and
     flows equal to the oracle's for every pair, and the same bytes as the two fixed modes -- for one and two
     levels and with the half-pixel step."""
@@ -344,10 +344,11 @@ def test_adaptive16_is_the_default_and_judges_every_pair_by_itself(aof, orc, syn
         blocks, flows, _ = eng.flow_batch(tp, tc, workspace=ws)
         torch.cuda.synchronize()
         hints = ws[L.hints:L.hints + 4 * 7].cpu().numpy().view(np.uint32)
-        assert set(hints.tolist()) <= {0, 1, 2}
+        assert set(hints.tolist()) <= {0, 1, 2, 3, 4}
         assert hints[0] == 2 and hints[2] == 2, hints          # noise-free translations: pruning pays, on one-row bounds
         assert hints[6] == 1, hints                            # +-3 LSB: pruning pays, on the two-row bounds
-        assert hints[1] == 0 and hints[3] == 0 and hints[4] == 0, hints   # noise / unrelated frames: it does not
+        assert hints[1] in (0, 3, 4) and hints[3] in (0, 3, 4), hints     # +-40 LSB: deeper bounds or none
+        assert hints[4] == 0 and hints[5] == 0, hints          # unrelated frames, a flat pair: nothing to prune with
         got = dict(blocks=aof.blocks_view(blocks), flows=aof.flows_view(flows))
         po = orc.params_from(p)
         for i in range(7):
