@@ -506,8 +506,12 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
 // would survive the bounds: a row survives when its bound does not exceed kFullOverBound times the block's
 // smallest bound -- the complete SAD of the best row is several times its two-row share (up to 8x when the
 // residual is noise), and a row whose bound already exceeds the best complete SAD can be dropped.  More than
-// kMaxSurvivorsPct of them: hints[pair] = 0 (run the exhaustive scan), else 1.  A heuristic about SPEED
-// only: both branches of the search kernel write the same records.
+// kMaxSurvivorsPct of them: the pair would run the exhaustive scan, else hints[pair] = 1 -- or 2 where ONE row already separates
+// the candidates (kFullOverOneRow, kMaxOneRowSurvivorsPct).  A pair that would run the exhaustive scan gets a deeper look at
+// every other sample block: the row with the smallest two-row bound is evaluated completely (step B1's result), the four- and
+// the eight-row bounds of the block's items are summed in one pass, and the rows at or below the evaluated SAD are counted --
+// few enough of them: hints[pair] = 3 (step A on four-row bounds) or 4 (eight rows), else 0.  A verdict about SPEED only:
+// every branch of the search kernel writes the same records.
 __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, uint32_t *hints, int stride_x, int stride_y)
 {
     __shared__ uint16_t s_bound[kProbeMaxBlocks][kSide + 1], s_bound1[kProbeMaxBlocks][kSide + 1];   // two-row, one-row bounds
