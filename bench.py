@@ -1176,6 +1176,7 @@ def main():
                            ("c3_noise16", ["--workload", "c3", "--noise", "16"]),
                            ("c3_realistic", ["--workload", "c3", "--input", "realistic"]),
                            ("c5", ["--workload", "c5", "--pairs", "256"]),
+                           ("c5_noise8", ["--workload", "c5", "--pairs", "256", "--noise", "8"]),
                            ("c5_realistic", ["--workload", "c5", "--pairs", "256", "--input", "realistic"])):
             cmd = [sys.executable, os.path.abspath(__file__)] + extra + [
                 "--steps", str(args.steps), "--warmup", str(args.warmup), "--settle-steps", str(args.settle_steps if args.settle_steps >= 0 else 300),
