@@ -1076,6 +1076,16 @@ def main():
     if eng.variant == "lane8" and head_mode == aof.SEARCH_ADAPTIVE:
         # which kernel the context's launches ran (ADAPTIVE 8x8: decided per launch from the pruned kernel's own reports)
         out["config"]["adaptive_search"] = eng.search_stats()
+    if eng.variant == "tile16_lds" and head_mode == aof.SEARCH_ADAPTIVE:
+        # ADAPTIVE 16x16: the probe's verdict per pair of the last launch (aof_ws_layout.hints): 0 = exhaustive scan, 1 / 2 / 3 / 4 =
+        # pruned on two- / one- / four- / eight-row lower bounds
+        try:
+            L_ = aof.workspace_layout(p, n)
+            hv = run.lanes[0].ws[L_.hints:L_.hints + 4 * n].cpu().numpy().view("uint32")
+            out["config"]["adaptive_search"] = {"verdicts": {str(k): int((hv == k).sum()) for k in range(5) if (hv == k).any()},
+                                                "legend": "0 exhaustive, 1 two-row, 2 one-row, 3 four-row, 4 eight-row bounds"}
+        except Exception as e:
+            out["config"]["adaptive_search"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     pruned_available = (eng.variant == "lane8" and eng.nblocks(0) > 256) or eng.variant == "tile16_lds"
     if args.search == "auto" and pruned_available and not args.force_generic and args.legs == "all":
         others = [m for m in (aof.SEARCH_EXHAUSTIVE, aof.SEARCH_PRUNED, aof.SEARCH_ADAPTIVE) if m != head_mode]
