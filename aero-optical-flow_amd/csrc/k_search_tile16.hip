@@ -50,6 +50,10 @@ constexpr uint32_t kMaxOneRowSurvivorsPct = 4;
 // row completely (what step B1 will do) and counts the rows whose deeper bound does not exceed THAT -- the survivors the search
 // will really have.  A verdict needs the expected work -- step A + the survivors' sums -- well under the exhaustive scan's.
 constexpr uint32_t kMaxFourRowSurvivorsPct = 40, kMaxEightRowSurvivorsPct = 10;
+// The deeper look costs the probe 22 us per 256 pairs (its loads are scattered): it is spared where the best row does not stand
+// out of its block's two-row bounds at all -- its bound in per mille of their mean: +-8 LSB 210, +-16 LSB 390 (eight rows still
+// pay there), +-24 LSB 543, +-40 LSB 738, the realistic input 683 (no depth pays from there on).
+constexpr uint32_t kMaxSeparationForDeeperLook = 450;
 constexpr int kRefineParts = 4;  // lanes per block in the half-pixel refinement (1: 3.56, 2: 3.31, 4: 3.28 ms per 1 024 c5h pairs)
 
 __device__ __forceinline__ u64 qsad(u64 window, uint32_t ref, u64 acc)
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
     const int delta = equalise_delta(a.sums, pair, a.level, (uint32_t)(W * a.h));
     // ADAPTIVE (a.prune == 2): the probe kernel in front of this launch has judged the pair (a.hints); PRUNED: always
     typedef const __attribute__((address_space(4))) uint32_t *const_u32;   // (scalar load: uniform in the workgroup)
-    const uint32_t hint = PRUNE ? (a.prune != 2 ? 1u : ((const_u32)a.hints)[pair]) : 0u;   // 0: exhaustive scan; 1, 2, 3, 4: step A on two-, one-, four-, eight-row bounds
+    const uint32_t hint = PRUNE ? (a.prune != 2 ? 1u : ((const_u32)a.hints)[pair] & 0xFFu) : 0u;   // 0: exhaustive scan; 1, 2, 3, 4: step A on two-, one-, four-, eight-row bounds
     const bool pays = hint != 0u;
 
     // Level 0 under a predictor (px, py): the block row's windows move by py rows and px columns.
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void k_search_tile16(SearchArgs a, uint32
 __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, uint32_t *hints, int stride_x, int stride_y)
 {
     __shared__ uint16_t s_bound[kProbeMaxBlocks][kSide + 1], s_bound1[kProbeMaxBlocks][kSide + 1];   // two-row, one-row bounds
-    __shared__ uint32_t s_tot[3];
+    __shared__ uint32_t s_tot[5];   // survivors (two-row), rows, survivors (one-row); sum of the blocks' smallest two-row bounds, of all of them
     const int64_t pair = blockIdx.x;
     const int tid = threadIdx.x, W = a.w, nx = a.grid.nx, ny = a.grid.ny;
     const int sx = probe_samples(nx, stride_x), sy = probe_samples(ny, stride_y);   // blocks stride/2, + stride, ... per axis
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
     const int H = a.h - 2 * org, Wb = W - 2 * org;
     const uint8_t *prev = a.prev + pair * a.pair_stride + (int64_t)org * (W + 1);
     const uint8_t *cur = a.cur + pair * a.pair_stride + (int64_t)org * (W + 1);
-    if (tid < 3) s_tot[tid] = 0;
+    if (tid < 5) s_tot[tid] = 0;
     for (int s = tid; s < kSide * nsamp; s += kProbeThreads) {
         const int blk = s / kSide, dyi = s - blk * kSide;
         const int by = (blk / sx) * stride_y + stride_y / 2, bx = (blk % sx) * stride_x + stride_x / 2;
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
         s_bound1[blk][dyi] = (uint16_t)bound1;
     }
     __syncthreads();
-    uint32_t would_survive = 0, would_survive1 = 0, rows = 0;
+    uint32_t would_survive = 0, would_survive1 = 0, rows = 0, smallest2 = 0, all2 = 0;
     for (int blk = tid; blk < nsamp; blk += kProbeThreads) {
         uint32_t m = 0xFFFFu, m1 = 0xFFFFu;
 #pragma unroll
@@ -553,7 +557,9 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
         for (int d = 0; d < kSide; d++) {
             would_survive += (uint32_t)s_bound[blk][d] <= limit ? 1u : 0u;
             would_survive1 += (uint32_t)s_bound1[blk][d] <= limit1 ? 1u : 0u;
+            all2 += (uint32_t)s_bound[blk][d];
         }
+        smallest2 += m;
         would_survive -= 1;            // (the best row itself is evaluated completely either way)
         would_survive1 -= 1;
         rows += kSide - 1;
@@ -561,13 +567,21 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
     would_survive = wave_sum_u32(would_survive);
     would_survive1 = wave_sum_u32(would_survive1);
     rows = wave_sum_u32(rows);
-    if ((tid & 63) == 0) { atomicAdd(&s_tot[0], would_survive); atomicAdd(&s_tot[1], rows); atomicAdd(&s_tot[2], would_survive1); }
+    smallest2 = wave_sum_u32(smallest2);
+    all2 = wave_sum_u32(all2);
+    if ((tid & 63) == 0) {
+        atomicAdd(&s_tot[0], would_survive); atomicAdd(&s_tot[1], rows); atomicAdd(&s_tot[2], would_survive1);
+        atomicAdd(&s_tot[3], smallest2); atomicAdd(&s_tot[4], all2);
+    }
     __syncthreads();
+    // how far the best row's two-row bound lies under the mean of its block's, in per mille (0: perfect matches; 1000: nothing
+    // stands out) -- a diagnostic in the verdict word's upper bits
+    const uint32_t separation = s_tot[4] != 0 ? (uint32_t)(((uint64_t)s_tot[3] * kSide * 1000u) / s_tot[4]) : 0u;
     uint32_t hint = (s_tot[1] != 0 && 100u * s_tot[0] > kMaxSurvivorsPct * s_tot[1]) ? 0u : 1u;   // (uniform: LDS totals)
     if (hint == 1u && s_tot[1] != 0 && 100u * s_tot[2] <= kMaxOneRowSurvivorsPct * s_tot[1]) hint = 2u;
     // two rows do not separate the candidates: do four, do eight?  (Only these pairs pay for the deeper sums -- their search
     // takes twice as long as a clean pair's anyway.)
-    if (hint == 0u && s_tot[1] != 0) {   // (uniform)
+    if (hint == 0u && s_tot[1] != 0 && separation <= kMaxSeparationForDeeperLook) {   // (uniform)
         __shared__ uint16_t s_full[kProbeMaxBlocks];   // the sample blocks' best SAD after step B1: the row with the smallest two-row bound, complete
         __syncthreads();
         if (tid < 3) s_tot[tid] = 0;
@@ -646,7 +660,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_tile16_probe(SearchArgs a, ui
         if (s_tot[1] != 0 && 100u * s_tot[0] <= kMaxFourRowSurvivorsPct * s_tot[1]) hint = 3u;
         else if (s_tot[1] != 0 && 100u * s_tot[2] <= kMaxEightRowSurvivorsPct * s_tot[1]) hint = 4u;
     }
-    if (tid == 0) hints[pair] = hint;
+    if (tid == 0) hints[pair] = hint | (separation << 8);   // (low byte: the verdict)
 }
 
 size_t tile16_lds(const SearchArgs &a)

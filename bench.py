@@ -1081,9 +1081,11 @@ def main():
         # pruned on two- / one- / four- / eight-row lower bounds
         try:
             L_ = aof.workspace_layout(p, n)
-            hv = run.lanes[0].ws[L_.hints:L_.hints + 4 * n].cpu().numpy().view("uint32")
+            hw = run.lanes[0].ws[L_.hints:L_.hints + 4 * n].cpu().numpy().view("uint32")
+            hv = hw & 0xFF
             out["config"]["adaptive_search"] = {"verdicts": {str(k): int((hv == k).sum()) for k in range(5) if (hv == k).any()},
-                                                "legend": "0 exhaustive, 1 two-row, 2 one-row, 3 four-row, 4 eight-row bounds"}
+                                                "legend": "0 exhaustive, 1 two-row, 2 one-row, 3 four-row, 4 eight-row bounds",
+                                                "separation_permille_median": int(sorted((hw >> 8).tolist())[len(hw) // 2])}
         except Exception as e:
             out["config"]["adaptive_search"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     pruned_available = (eng.variant == "lane8" and eng.nblocks(0) > 256) or eng.variant == "tile16_lds"

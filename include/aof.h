@@ -91,7 +91,7 @@ typedef struct aof_ws_layout {
     size_t l0_subdirs;/* u8 [n_pairs][nb0] when the caller passes none */
     size_t l0_hist;   /* u32 [n_pairs][chunks0][2][bins0]: per-chunk vote histograms (grids beyond 8 192 blocks) */
     size_t l1_hist;   /* u32 [n_pairs][chunks1][2][bins1] */
-    size_t hints;     /* u32 [n_pairs], 16x16 tiles: the adaptive search's per-pair verdict (0 = exhaustive scan; 1 / 2 / 3 / 4 = pruning pays, on two- / one- / four- / eight-row bounds) */
+    size_t hints;     /* u32 [n_pairs], 16x16 tiles: the adaptive search's per-pair verdict low byte (0 = exhaustive scan; 1 / 2 / 3 / 4 = pruning pays, on two- / one- / four- / eight-row bounds), a diagnostic above it */
 } aof_ws_layout;
 
 typedef struct aof_ctx aof_ctx;

@@ -343,7 +343,7 @@ def test_adaptive16_is_the_default_and_judges_every_pair_by_itself(aof, orc, syn
         ws = torch.full((L.total_bytes,), 0x5A, dtype=torch.uint8, device=gpu_device)
         blocks, flows, _ = eng.flow_batch(tp, tc, workspace=ws)
         torch.cuda.synchronize()
-        hints = ws[L.hints:L.hints + 4 * 7].cpu().numpy().view(np.uint32)
+        hints = ws[L.hints:L.hints + 4 * 7].cpu().numpy().view(np.uint32) & 0xFF   # (upper bits: the probe's separation figure)
         assert set(hints.tolist()) <= {0, 1, 2, 3, 4}
         assert hints[0] == 2 and hints[2] == 2, hints          # noise-free translations: pruning pays, on one-row bounds
         assert hints[6] == 1, hints                            # +-3 LSB: pruning pays, on the two-row bounds
